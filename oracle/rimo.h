@@ -1,0 +1,134 @@
+/* rimo.h -- CPU oracle for the rimphony hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This directory restates, in plain C, the per-parameter-point algorithm of
+ * pkgw/rimphony (symphony.rs, heyvaerts.rs, gsl.rs + the GSL routines they
+ * call, the four distribution functions, and leung-bessel/src/bessel.c) so
+ * that the HIP kernels can be checked against it.  Nothing in the product
+ * (rimphony_amd/, include/) may call, link or import anything from here; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Pinning: the Rust crate cannot be built here (no
+ * cargo/rustc, no GSL, special-fun un-vendored) and bessel.c needs the absent
+ * <gsl/gsl_sf_bessel.h>, so there is no oracle/_ref.  The oracle is pinned by
+ * the reference's own fixtures: tests/symphony-powerlaw.txt (200 x 6
+ * coefficients, 1 %), the Faraday known answers in power_law.rs:209-240 and
+ * thermal_juettner.rs:174-210 (1 %), normalisation = 1, pitchy_pl(k=0) ==
+ * power_law, the finite-difference derivative checks and the n<30 Bessel
+ * smoke values -- see tests/test_oracle_*.py.  pitchy_kappa coefficients have
+ * no absolute fixture in the reference: parity unpinned for those.
+ *
+ * Arithmetic: two builds of the same sources.
+ *   liboracle.so       elementary functions from rimphony_amd/csrc/detmath.h
+ *                      and GK31 sums in the fixed 32-leaf tree order the
+ *                      wavefront kernel uses -> comparable BIT FOR BIT with
+ *                      the GPU.
+ *   liboracle_libm.so  (-DRIMO_LIBM) glibc libm and GSL's sequential GK31
+ *                      summation order, i.e. as close to the Rust/GSL binary
+ *                      as can be had here; used to show that the two choices
+ *                      above move results only at rounding level.
+ */
+#ifndef RIMO_H
+#define RIMO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* lib.rs:74-107 */
+enum { RIMO_STOKES_I = 0, RIMO_STOKES_Q = 1, RIMO_STOKES_V = 2 };
+enum { RIMO_EMISSION = 0, RIMO_ABSORPTION = 1, RIMO_FARADAY = 2 };
+
+/* distribution kinds and their parameter vectors (same order as the C ABI) */
+enum {
+    RIMO_POWER_LAW = 0,        /* p, gamma_min, gamma_max, gamma_cutoff        power_law.rs:27-33   */
+    RIMO_THERMAL_JUETTNER = 1, /* T                                             thermal_juettner.rs:23-26 */
+    RIMO_PITCHY_PL = 2,        /* p, k, gamma_min, gamma_max, gamma_cutoff      pitchy_pl.rs:22-29  */
+    RIMO_PITCHY_KAPPA = 3      /* kappa, width, k, gamma_cutoff                 pitchy_kappa.rs:28-35 */
+};
+#define RIMO_MAX_PARAMS 6
+
+typedef struct {
+    int kind;
+    double par[RIMO_MAX_PARAMS];
+    double inv_gamma_cutoff;
+    double inv_kappa_width;
+    double neg_inverse_t;
+    double norm;
+} rimo_dist;
+
+/* GSL status codes used by the path (gsl_errno.h values) */
+enum { RIMO_SUCCESS = 0, RIMO_EFAILED = 5, RIMO_EMAXITER = 11, RIMO_EBADTOL = 13, RIMO_EROUND = 18, RIMO_ESING = 21 };
+
+/* work counters: the algorithmic-work figures of SURVEY.md 8(d) */
+typedef struct {
+    uint64_t integrand_evals;   /* gamma_integrand / heyvaerts element samples */
+    uint64_t gk_evals;          /* 31-point rule applications (inner integrals) */
+    uint64_t inner_qag_calls;   /* gamma_integral / inner sigma|pomega QAGs      */
+    uint64_t outer_gk_evals;    /* 31-point rule applications of outer QAGs     */
+    uint64_t outer_qag_calls;   /* n-chunks / outer Heyvaerts QAGs              */
+    uint64_t deriv_calls;
+    uint64_t max_inner_size;    /* largest subinterval count seen               */
+    uint64_t max_outer_size;
+    uint64_t bessel_calls;
+    uint64_t norm_evals;
+} rimo_counters;
+
+typedef double (*rimo_fn)(double x, void *ctx);
+
+/* --- gsl.rs:58-70, 156-257 + the GSL algorithms behind them ------------- */
+typedef struct {
+    size_t limit, size, nrmax, i, maximum_level;
+    double *alist, *blist, *rlist, *elist;
+    size_t *order, *level;
+} rimo_workspace;
+rimo_workspace *rimo_workspace_alloc(size_t limit);   /* gsl_integration_workspace_alloc */
+void rimo_workspace_free(rimo_workspace *w);
+
+/* gsl_integration_qag(..., key = 3 (GK31), ...): returns a GSL status; the Rust
+ * wrapper turns any non-zero status into Err (gsl.rs:198-199). */
+int rimo_qag(rimo_fn f, void *ctx, double a, double b, double epsabs, double epsrel,
+             size_t limit, rimo_workspace *w, double *result, double *abserr, uint64_t *gk_evals);
+/* convenience for tests: allocates its own workspace */
+int rimo_qag_gk31(rimo_fn f, void *ctx, double a, double b, double epsabs, double epsrel,
+                  size_t limit, double *result, double *abserr, size_t *size_out, uint64_t *gk_evals);
+void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
+               double *result, double *abserr, double *resabs, double *resasc);
+int rimo_deriv_central(rimo_fn f, void *ctx, double x, double h, double *result, double *abserr);
+double rimo_hyperg_2F1_at_1(double a, double b, double c);
+
+/* --- leung-bessel ------------------------------------------------------ */
+double rimo_bessel_j(double n, double x);   /* pkgw_bessel_j  bessel.c:318-376 */
+double rimo_bessel_dj(double n, double x);  /* pkgw_bessel_dj bessel.c:379-405 */
+double rimo_bessel_jn_int(int n, double x); /* stands in for gsl_sf_bessel_Jn  */
+
+/* --- distributions ----------------------------------------------------- */
+int rimo_dist_init(rimo_dist *d, int kind, const double *params); /* new()+limits+full_calculation(): 0 or GSL status */
+double rimo_calc_f(const rimo_dist *d, double gamma, double cos_xi);
+void rimo_calc_f_derivatives(const rimo_dist *d, double gamma, double cos_xi, double *dfdg, double *dfdcx);
+
+/* --- calculators -------------------------------------------------------- */
+double rimo_symphony(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c);
+double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c);
+double rimo_compute_dimensionless(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c);
+void rimo_compute_all_dimensionless(const rimo_dist *d, double s, double theta, double out[8], rimo_counters *c);
+double rimo_compute_cgs(const rimo_dist *d, int coeff, int stokes, double nu, double b, double n_e, double theta);
+
+/* diagnostics (lib.rs:254-298) */
+double rimo_gamma_integrand(const rimo_dist *d, int coeff, int stokes, double s, double theta, double n, double gamma);
+double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta, double n);
+
+/* batch: N x (full_calculation + selected coefficients); params SoA [nparams][n];
+ * out [n][8] row-major in the order of lib.rs:176-177; counters may be NULL
+ * (else one struct summed over the batch). nthreads<=1: serial. */
+int rimo_batch(int kind, size_t n, const double *s, const double *theta, const double *const *params,
+               uint32_t coeff_mask, double *out, rimo_counters *counters, int nthreads);
+
+const char *rimo_build_flavour(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

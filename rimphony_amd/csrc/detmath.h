@@ -1,0 +1,315 @@
+/* detmath.h -- deterministic fp64 elementary functions (C99 / C++ / HIP).
+ *
+ * Why this exists.  The reference hot path (src/symphony.rs:196-295) takes
+ * control-flow decisions on noise-level quantities (a finite difference of an
+ * eps_rel=1e-3 quadrature, symphony.rs:238-246).  A last-bit difference in
+ * exp/log/pow between glibc (CPU) and ocml (GPU) can flip such a decision and
+ * move the result by ~1e-5.  To make "GPU == CPU oracle" a bit-for-bit
+ * statement instead of a statistical one, every transcendental used on the
+ * path is written here using only IEEE-754 correctly-rounded primitives
+ * (+ - * / sqrt fma, rint, ldexp), which gcc/x86-64 and hipcc/gfx950 evaluate
+ * identically when both are built with -ffp-contract=off.  The same header is
+ * compiled into the HIP kernels (rimphony_amd/csrc) and into the CPU oracle
+ * (oracle/), so the two can only differ in control flow and data movement --
+ * exactly what the parity tests are meant to check.  The functions themselves
+ * are validated against mpmath/libm in tests/test_detmath.py (<= 1.5 ulp).
+ *
+ * All routines are plain Taylor/Stirling series with exactly representable
+ * rational coefficients; no tables, no memory traffic.
+ */
+#ifndef RIM_DETMATH_H
+#define RIM_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RIM_FN __host__ __device__ static inline
+#else
+#define RIM_FN static inline
+#endif
+
+#define RIM_NAN (__builtin_nan(""))
+#define RIM_INF (__builtin_inf())
+#define RIM_PI 3.14159265358979323846
+#define RIM_DBL_EPSILON 2.2204460492503131e-16
+#define RIM_DBL_MIN 2.2250738585072014e-308
+
+RIM_FN uint64_t rim_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+RIM_FN double rim_frombits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+RIM_FN double rim_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RIM_FN double rim_sqrt(double x) { return __builtin_sqrt(x); }
+RIM_FN double rim_fabs(double x) { return __builtin_fabs(x); }
+RIM_FN double rim_floor(double x) { return __builtin_floor(x); }
+RIM_FN int rim_isnan(double x) { return x != x; }
+RIM_FN int rim_isfinite(double x) { return (rim_bits(x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull; }
+RIM_FN double rim_max(double a, double b) { return a > b ? a : b; } /* GSL_MAX_DBL semantics */
+RIM_FN double rim_min(double a, double b) { return a < b ? a : b; }
+
+/* x * 2^k, exact unless the result is subnormal (then one rounding). */
+RIM_FN double rim_ldexp(double x, int k) { return __builtin_ldexp(x, k); }
+
+/* ---- exp ------------------------------------------------------------- */
+
+/* exp(xh + xl) for |xl| << |xh|; one ulp class accuracy (< 0.6 ulp). */
+RIM_FN double rim_exp_dd(double xh, double xl)
+{
+    if (rim_isnan(xh)) return xh;
+    if (xh > 709.782712893384) return RIM_INF;
+    if (xh < -745.2) return 0.0;
+
+    /* k = nearest integer to x / ln 2 */
+    const double kd = __builtin_rint(xh * 1.44269504088896338700e+00);
+    const int k = (int) kd;
+    /* ln2 = LN2_HI + LN2_LO; LN2_HI has 21 trailing zero bits so kd*LN2_HI is exact */
+    double r = rim_fma(-kd, 6.93147180369123816490e-01, xh);
+    r = rim_fma(-kd, 1.90821492927058770002e-10, r);
+    r = r + xl;
+
+    /* exp(r) = 1 + r + r^2 * (1/2 + r/6 + ... + r^11/13!),  |r| <= 0.3466 */
+    double q = 1.0 / 6227020800.0;              /* 1/13! */
+    q = rim_fma(q, r, 1.0 / 479001600.0);      /* 1/12! */
+    q = rim_fma(q, r, 1.0 / 39916800.0);
+    q = rim_fma(q, r, 1.0 / 3628800.0);
+    q = rim_fma(q, r, 1.0 / 362880.0);
+    q = rim_fma(q, r, 1.0 / 40320.0);
+    q = rim_fma(q, r, 1.0 / 5040.0);
+    q = rim_fma(q, r, 1.0 / 720.0);
+    q = rim_fma(q, r, 1.0 / 120.0);
+    q = rim_fma(q, r, 1.0 / 24.0);
+    q = rim_fma(q, r, 1.0 / 6.0);
+    q = rim_fma(q, r, 0.5);
+    const double t = rim_fma(q * r, r, r);     /* r + r^2 q */
+    const double p = 1.0 + t;
+    return rim_ldexp(p, k);
+}
+
+RIM_FN double rim_exp(double x) { return rim_exp_dd(x, 0.0); }
+
+/* ---- log ------------------------------------------------------------- */
+
+/* log(x) as an unevaluated sum hi + lo with ~2^-60 relative accuracy and
+ * hi = round-to-nearest(hi + lo).  Domain handling: x < 0 -> NaN, 0 -> -inf. */
+RIM_FN double rim_log_dd(double x, double *lo)
+{
+    *lo = 0.0;
+    if (rim_isnan(x)) return x;
+    if (x < 0.0) return RIM_NAN;
+    if (x == 0.0) return -RIM_INF;
+    if (!rim_isfinite(x)) return x;
+
+    int k = 0;
+    uint64_t u = rim_bits(x);
+    if ((u >> 52) == 0) {            /* subnormal: scale by 2^54 */
+        x = x * 18014398509481984.0;
+        u = rim_bits(x);
+        k = -54;
+    }
+    k += (int) (u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = rim_frombits(u);      /* [1, 2) */
+    if (m > 1.4142135623730951) { m = 0.5 * m; k += 1; }   /* [0.7071, 1.4142] */
+
+    const double f = m - 1.0;        /* exact */
+    /* s = f / (2 + f) in double-double */
+    const double th = 2.0 + f;
+    const double tl = (2.0 - th) + f;            /* exact (Fast2Sum, 2 >= |f|) */
+    const double rcp = 1.0 / th;
+    const double sh = f * rcp;
+    double res = rim_fma(-sh, th, f);
+    res = rim_fma(-sh, tl, res);
+    const double sl = res * rcp;
+
+    /* atanh(s)/s - 1 = z/3 + z^2/5 + ... + z^11/23,  z = s^2 <= 0.0295 */
+    const double z = sh * sh;
+    double q = 1.0 / 23.0;
+    q = rim_fma(q, z, 1.0 / 21.0);
+    q = rim_fma(q, z, 1.0 / 19.0);
+    q = rim_fma(q, z, 1.0 / 17.0);
+    q = rim_fma(q, z, 1.0 / 15.0);
+    q = rim_fma(q, z, 1.0 / 13.0);
+    q = rim_fma(q, z, 1.0 / 11.0);
+    q = rim_fma(q, z, 1.0 / 9.0);
+    q = rim_fma(q, z, 1.0 / 7.0);
+    q = rim_fma(q, z, 1.0 / 5.0);
+    q = rim_fma(q, z, 1.0 / 3.0);
+    q = q * z;
+
+    /* log m = 2 sh + (2 sl + 2 sh q) */
+    const double a = 2.0 * sh;
+    const double c = rim_fma(a, q, 2.0 * sl);
+
+    /* + k ln2, ln2 = LN2_HI + LN2_LO with k*LN2_HI exact */
+    const double kd = (double) k;
+    const double kh = kd * 6.93147180369123816490e-01;
+    const double kl = kd * 1.90821492927058770002e-10;
+    /* TwoSum(kh, a) */
+    const double s1 = kh + a;
+    const double bb = s1 - kh;
+    const double e1 = (kh - (s1 - bb)) + (a - bb);
+    const double low = e1 + (c + kl);
+    const double hi = s1 + low;
+    *lo = (s1 - hi) + low;
+    return hi;
+}
+
+RIM_FN double rim_log(double x) { double lo; return rim_log_dd(x, &lo); }
+
+RIM_FN double rim_log10(double x)
+{
+    double lo;
+    const double hi = rim_log_dd(x, &lo);
+    if (!rim_isfinite(hi)) return hi;
+    /* 1/ln(10) = C_HI + C_LO */
+    const double C_HI = 4.34294481903251816668e-01;
+    const double C_LO = 1.09831965021676507340e-17;
+    const double p = hi * C_HI;
+    const double e = rim_fma(hi, C_HI, -p);
+    return p + (e + rim_fma(hi, C_LO, lo * C_HI));
+}
+
+/* ---- pow ------------------------------------------------------------- */
+
+RIM_FN double rim_pow(double x, double y)
+{
+    if (y == 0.0) return 1.0;
+    if (x == 1.0) return 1.0;
+    if (rim_isnan(x) || rim_isnan(y)) return RIM_NAN;
+
+    double sign = 1.0;
+    if (x < 0.0 || (x == 0.0 && (rim_bits(x) >> 63))) {
+        /* negative base: only integer exponents are defined */
+        const double yi = rim_floor(y);
+        const int y_is_int = (yi == y) && rim_isfinite(y);
+        if (x != 0.0 && !y_is_int) {
+            if (!rim_isfinite(y)) {
+                /* (-a)^(+-inf) */
+                const double ax = -x;
+                if (ax == 1.0) return 1.0;
+                return ((ax > 1.0) == (y > 0.0)) ? RIM_INF : 0.0;
+            }
+            return RIM_NAN;
+        }
+        if (y_is_int && rim_fabs(y) < 9007199254740992.0) {
+            const double half = 0.5 * y;
+            if (rim_floor(half) != half) sign = -1.0;
+        }
+        x = -x;
+    }
+
+    if (x == 0.0) return (y > 0.0) ? sign * 0.0 : sign * RIM_INF;
+    if (!rim_isfinite(x)) return (y > 0.0) ? sign * RIM_INF : sign * 0.0;
+    if (!rim_isfinite(y)) {
+        if (x == 1.0) return 1.0;
+        return ((x > 1.0) == (y > 0.0)) ? RIM_INF : 0.0;
+    }
+
+    double ll;
+    const double lh = rim_log_dd(x, &ll);
+    const double ph = y * lh;
+    const double pl = rim_fma(y, lh, -ph) + y * ll;
+    if (ph > 800.0) return sign * RIM_INF;
+    if (ph < -800.0) return sign * 0.0;
+    return sign * rim_exp_dd(ph, pl);
+}
+
+/* ---- lgamma (positive arguments only) --------------------------------- */
+
+/* Stirling series for x >= 16 (error of the truncated series < 1e-19 rel). */
+RIM_FN double rim_lgamma_stirling(double x)
+{
+    double ll;
+    const double lh = rim_log_dd(x, &ll);
+    /* (x - 1/2) * log x in double-double */
+    const double xm = x - 0.5;                    /* exact for x >= 1 below 2^52 */
+    const double ph = xm * lh;
+    const double pl = rim_fma(xm, lh, -ph) + xm * ll;
+    /* asymptotic tail: sum B_2k / (2k (2k-1) x^(2k-1)), k = 1..7 */
+    const double w = 1.0 / x;
+    const double w2 = w * w;
+    double t = 1.0 / 156.0;
+    t = rim_fma(t, w2, -691.0 / 360360.0);
+    t = rim_fma(t, w2, 1.0 / 1188.0);
+    t = rim_fma(t, w2, -1.0 / 1680.0);
+    t = rim_fma(t, w2, 1.0 / 1260.0);
+    t = rim_fma(t, w2, -1.0 / 360.0);
+    t = rim_fma(t, w2, 1.0 / 12.0);
+    t = t * w;
+    /* ph - x + (pl + t + 0.5 log(2 pi)) */
+    const double HALF_LOG_2PI = 9.18938533204672741780e-01;
+    const double d = ph - x;
+    const double bv = d - ph;
+    const double e = (ph - (d - bv)) + (-x - bv);     /* TwoSum(ph, -x) */
+    return d + (e + (pl + (t + HALF_LOG_2PI)));
+}
+
+RIM_FN double rim_lgamma_pos(double x)
+{
+    if (rim_isnan(x) || x <= 0.0) return RIM_NAN;
+    if (!rim_isfinite(x)) return x;
+    if (x >= 16.0) return rim_lgamma_stirling(x);
+    /* shift up: Gamma(x) = Gamma(x + m) / (x (x+1) ... (x+m-1)) */
+    double prod = 1.0;
+    while (x < 16.0) { prod = prod * x; x = x + 1.0; }
+    return rim_lgamma_stirling(x) - rim_log(prod);
+}
+
+/* ---- sin / cos --------------------------------------------------------- */
+
+/* Accurate (< 1 ulp) for |x| <= 1e5; beyond that the Cody-Waite reduction
+ * gradually loses bits (the reference only ever uses observer angles in
+ * [0, pi]). */
+RIM_FN void rim_sincos(double x, double *sn, double *cs)
+{
+    if (!rim_isfinite(x)) { *sn = RIM_NAN; *cs = RIM_NAN; return; }
+    const double kd = __builtin_rint(x * 6.36619772367581382433e-01); /* 2/pi */
+    const long long kq = (long long) kd;
+    /* pi/2 = P1 + P2 + P2T; P1, P2 carry 33 significant bits so kd*P1, kd*P2 are exact */
+    const double r1 = rim_fma(-kd, 1.57079632673412561417e+00, x);
+    const double wa = kd * 6.07710050630396597660e-11;
+    double rh = r1 - wa;
+    double bv = rh - r1;
+    double rl = (r1 - (rh - bv)) + (-wa - bv);      /* TwoSum(r1, -wa) */
+    const double wb = kd * 2.02226624879595063154e-21;
+    {
+        const double t = rh;
+        rh = t - wb;
+        bv = rh - t;
+        rl = rl + ((t - (rh - bv)) + (-wb - bv));
+    }
+    const double z = rh * rh;
+    /* sin(r) = r + r^3 S(z), cos(r) = 1 - z/2 + z^2 C(z) */
+    double s = 1.0 / 121645100408832000.0;           /* 1/19! */
+    s = rim_fma(s, z, -1.0 / 355687428096000.0);     /* 1/17! */
+    s = rim_fma(s, z, 1.0 / 1307674368000.0);        /* 1/15! */
+    s = rim_fma(s, z, -1.0 / 6227020800.0);
+    s = rim_fma(s, z, 1.0 / 39916800.0);
+    s = rim_fma(s, z, -1.0 / 362880.0);
+    s = rim_fma(s, z, 1.0 / 5040.0);
+    s = rim_fma(s, z, -1.0 / 120.0);
+    s = rim_fma(s, z, 1.0 / 6.0);                    /* note sign folded below */
+    double c = -1.0 / 6402373705728000.0;            /* -1/18! */
+    c = rim_fma(c, z, 1.0 / 20922789888000.0);       /* 1/16! */
+    c = rim_fma(c, z, -1.0 / 87178291200.0);
+    c = rim_fma(c, z, 1.0 / 479001600.0);
+    c = rim_fma(c, z, -1.0 / 3628800.0);
+    c = rim_fma(c, z, 1.0 / 40320.0);
+    c = rim_fma(c, z, -1.0 / 720.0);
+    c = rim_fma(c, z, 1.0 / 24.0);
+    /* sin r = rh - rh z s' with s' = 1/6 - z/120 + ... ; above built with
+     * alternating signs so that s = 1/6 - z/120 + z^2/5040 - ... */
+    const double sin_r = rim_fma(-(rh * z), s, rh);
+    const double hz = 0.5 * z;
+    const double wv = 1.0 - hz;
+    const double cos_r = wv + (((1.0 - wv) - hz) + (z * z) * c);
+    /* first-order correction for the low part of the reduced argument */
+    const double sv = rim_fma(rl, cos_r, sin_r);
+    const double cv = rim_fma(-rl, sin_r, cos_r);
+    switch ((int) (kq & 3)) {
+    case 0: *sn = sv; *cs = cv; break;
+    case 1: *sn = cv; *cs = -sv; break;
+    case 2: *sn = -sv; *cs = -cv; break;
+    default: *sn = -cv; *cs = sv; break;
+    }
+}
+
+#endif /* RIM_DETMATH_H */
