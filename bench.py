@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched synchrotron-coefficient hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): power-law distribution, the 1e6-point
+synthetic table of random (s, theta, p, gamma_min) defined in
+rimphony_amd/workload.py, coefficients j_I and alpha_I, fp64.  A "step" is one
+pass of the hot path (full_calculation + the selected coefficients) over one
+batch of `--points` consecutive table rows PER GPU; successive steps walk
+through the table.  With N GPUs the step's global batch of N*points rows is
+sharded interleaved (row i -> rank i mod N, no data-path collective during
+compute) and the output table is gathered to rank 0 with one RCCL gather inside
+the timed region.  Inputs are resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0).  `value` = parameter points per second, whole job.
+`roofline` is for the dominant kernel (symphony_kernel): algorithmic fp64 flops
+(device-counted integrand samples x the per-sample figure of DESIGN.md) over
+its HIP-event-measured duration, against the fp64 vector peak -- the path is
+VALU-bound, not HBM- or MFMA-bound, hence "bound": "valu_fp64".
+`cpu_baseline` times the oracle (a port, not the Rust binary) on the host cores
+over a bounded prefix of the same table.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# DESIGN.md "Algorithmic work per unit": fp64 flops per integrand sample
+# (power-law distribution; FMA = 2, add/mul/div/sqrt = 1), counted from the source.
+FLOPS_PER_SAMPLE = 800.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=32768, help="table rows per GPU per step")
+    ap.add_argument("--config", default="cfg2_powerlaw_jI_aI")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="points of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rimphony_amd import api, workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = api.Context(local_rank)
+    dev = torch.device("cuda", local_rank)
+    kind, mask, _, _, _ = workload.make_batch(args.config, 1)
+    nsel = bin(mask & 0x3F).count("1")
+
+    P = args.points
+    total_steps = args.warmup + args.steps
+    TABLE = 1_000_000
+
+    # stage every step's shard in HBM up front (inputs resident before timing)
+    shards = []
+    for st in range(total_steps):
+        start = (st * P * world) % TABLE
+        idx_global = np.arange(P * world)
+        _, _, s, th, params = workload.make_batch(args.config, P * world, start=start)
+        mine = idx_global % world == rank           # interleaved sharding
+        shards.append((torch.from_numpy(s[mine]).to(dev), torch.from_numpy(th[mine]).to(dev),
+                       [torch.from_numpy(p[mine]).to(dev) for p in params]))
+    gather_buf = [torch.empty((P, 8), dtype=torch.float64, device=dev) for _ in range(world)] \
+        if (distributed and rank == 0) else None
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    kernel_ms = []
+    samples = []
+
+    def run_step(i, record):
+        s, th, params = shards[i]
+        out, _ = ctx.compute_batch_device(kind, s, th, params, mask)
+        if distributed:
+            dist.gather(out, gather_buf, dst=0)
+        if record:
+            kernel_ms.append(ctx.last_symphony_ms())        # HIP events on the launch stream
+            samples.append(ctx.last_work()["samples"])
+        return out
+
+    for i in range(args.warmup):
+        run_step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        run_step(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        points = P * world * args.steps
+        value = points / elapsed
+        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        avg_samples = float(np.mean(samples))
+        achieved = avg_samples * FLOPS_PER_SAMPLE / avg_kernel_s / 1e12
+        roofline = {
+            "bound": "valu_fp64", "achieved": round(achieved, 4), "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / FP64_VECTOR_PEAK_TFLOPS, 5), "traffic": None,
+            "kernel": "symphony_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
+            "samples_per_launch": avg_samples, "flops_per_sample": FLOPS_PER_SAMPLE,
+        }
+
+        cpu = None
+        if args.cpu_sample > 0 and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_bind
+            L = oracle_bind.load("det")
+            cores = os.cpu_count() or 1
+            _, _, s, th, params = workload.make_batch(args.config, args.cpu_sample, start=0)
+            c0 = time.perf_counter()
+            oracle_bind.batch(L, kind, s, th, params, mask, nthreads=cores)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round(args.cpu_sample / cdt, 3), "unit": "points/s", "cores": cores, "kind": "port",
+                   "sample": "first %d rows of the same table, oracle/liboracle.so, OpenMP dynamic over points"
+                             % args.cpu_sample}
+
+        line = {
+            "metric": "parameter-points/sec (power law, j_I + alpha_I per point)",
+            "value": round(value, 2), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: power_law, 1e6-row random (s,theta,p,gamma_min) table, "
+                                   "j_I/alpha_I, fp64; step = %d rows per GPU" % P,
+                       "points_per_step_per_gpu": P, "coefficients_per_point": nsel,
+                       "coefficients_per_s": round(value * nsel, 2), "sharding": "interleaved, gather to rank 0"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/* rimphony_hip.h -- C ABI of the MI355X-native batched synchrotron-coefficient
+ * integrator (librimphony_hip.so).
+ *
+ * Scope: the per-parameter-point hot path of pkgw/rimphony, i.e. N times
+ *     D::new(..).gamma_limits(..).full_calculation(log)        (power_law.rs:71-111,
+ *         thermal_juettner.rs:45-72, pitchy_pl.rs:73-115, pitchy_kappa.rs:70-125)
+ *     .compute_all_dimensionless(s, theta)                     (src/lib.rs:178-191)
+ * evaluated on the GPU for a closed set of distribution functions.  The
+ * reference has no batch/FFI interface for this path; its two existing FFI
+ * seams are the leung-bessel extern block (leung-bessel/src/lib.rs:36-42) and
+ * the GSL callback trampoline (src/gsl.rs:111-117).  A device kernel cannot
+ * call back into a host closure, so the second seam is replaced by the
+ * `dist_kind` + SoA parameter arrays below; the first is kept as a batched
+ * entry point (rimphony_bessel_batch_device).  INTEGRATION.md shows the
+ * `-sys` crate a maintainer would add on the Rust side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream); `d_*` arguments are DEVICE pointers.
+ *   - return value: 0 on success, a negative RIMPHONY_E* code on API misuse or
+ *     a HIP failure (rimphony_strerror()).  Numerical failure is never an
+ *     error: as in the reference (symphony.rs:115-117,127,380) the affected
+ *     coefficient is NaN, and the optional status array says why.
+ *   - output slot order is that of lib.rs:176-177:
+ *         [j_I, alpha_I, j_Q, alpha_Q, j_V, alpha_V, rho_Q, rho_V]
+ *     Slots not selected in coeff_mask are written as NaN.
+ *   - results depend only on the inputs of a point, never on batch size,
+ *     launch geometry or which GPU evaluated it.
+ *   - the caller owns every buffer it passes; the library owns its workspace
+ *     through the opaque context and never returns memory to the caller.
+ */
+#ifndef RIMPHONY_HIP_H
+#define RIMPHONY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum Stokes (lib.rs:74-87) and enum Coefficient (lib.rs:91-107) */
+enum { RIMPHONY_STOKES_I = 0, RIMPHONY_STOKES_Q = 1, RIMPHONY_STOKES_V = 2 };
+enum { RIMPHONY_EMISSION = 0, RIMPHONY_ABSORPTION = 1, RIMPHONY_FARADAY = 2 };
+
+/* Distribution kinds; params are SoA arrays, one per parameter, in this order:
+ *   POWER_LAW         p, gamma_min, gamma_max, gamma_cutoff          (power_law.rs:27-33, 82-87)
+ *   THERMAL_JUETTNER  T                                              (thermal_juettner.rs:45-50)
+ *   PITCHY_PL         p, k, gamma_min, gamma_max, gamma_cutoff       (pitchy_pl.rs:73-90)
+ *   PITCHY_KAPPA      kappa, width, k, gamma_cutoff                  (pitchy_kappa.rs:70-85) */
+enum {
+    RIMPHONY_POWER_LAW = 0,
+    RIMPHONY_THERMAL_JUETTNER = 1,
+    RIMPHONY_PITCHY_PL = 2,
+    RIMPHONY_PITCHY_KAPPA = 3
+};
+int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unknown kind */
+
+/* coeff_mask bits = output slots */
+#define RIMPHONY_SLOT_J_I      (1u << 0)
+#define RIMPHONY_SLOT_ALPHA_I  (1u << 1)
+#define RIMPHONY_SLOT_J_Q      (1u << 2)
+#define RIMPHONY_SLOT_ALPHA_Q  (1u << 3)
+#define RIMPHONY_SLOT_J_V      (1u << 4)
+#define RIMPHONY_SLOT_ALPHA_V  (1u << 5)
+#define RIMPHONY_SLOT_RHO_Q    (1u << 6)
+#define RIMPHONY_SLOT_RHO_V    (1u << 7)
+#define RIMPHONY_SLOTS_ALL     0xffu
+
+/* per-coefficient status bits (0 = clean) */
+#define RIMPHONY_ST_INNER_FAIL  1   /* an inner QAG returned a GSL error -> NaN sample (symphony.rs:380) */
+#define RIMPHONY_ST_OUTER_FAIL  2   /* an outer (n / Heyvaerts) QAG failed (symphony.rs:269 `?`)        */
+#define RIMPHONY_ST_CHUNK_CAP   4   /* chunk-marching iteration cap hit                                  */
+#define RIMPHONY_ST_STORE_FULL  8   /* LDS subinterval store exhausted                                   */
+#define RIMPHONY_ST_NONFINITE   16  /* the coefficient is NaN                                            */
+#define RIMPHONY_ST_NORM_FAIL   32  /* normalisation integral failed (the reference would panic)         */
+#define RIMPHONY_ST_NOT_COMPUTED 64 /* slot not selected / not available                                 */
+
+/* error codes */
+#define RIMPHONY_OK         0
+#define RIMPHONY_EINVAL    -1
+#define RIMPHONY_EHIP      -2
+#define RIMPHONY_ENOMEM    -3
+#define RIMPHONY_ENODEVICE -4
+
+typedef struct rimphony_ctx rimphony_ctx;
+
+/* Create / destroy a context bound to one HIP device.  Fails with
+ * RIMPHONY_ENODEVICE when no GPU is present (there is no CPU fallback). */
+int rimphony_ctx_create(int device, rimphony_ctx **out);
+void rimphony_ctx_destroy(rimphony_ctx *ctx);
+const char *rimphony_strerror(int code);
+const char *rimphony_version(void);
+
+/* Work counters of the most recent batch call on this context (device-side
+ * counts, read back synchronously): integrand samples, wave-wide evaluation
+ * passes, inner QAG calls. */
+typedef struct {
+    uint64_t samples;
+    uint64_t passes;
+    uint64_t inner_qags;
+} rimphony_work;
+int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
+
+/* Duration of the most recent Symphony kernel launch of this context, measured
+ * with HIP events recorded on the stream the kernel was launched on (waits for
+ * the kernel to finish). */
+int rimphony_last_symphony_ms(rimphony_ctx *ctx, float *ms);
+
+/* The batched compute(): N x (full_calculation + compute_all_dimensionless).
+ *   d_s, d_theta   [n]                device
+ *   d_params       host array of rimphony_dist_nparams(kind) DEVICE pointers, each [n]
+ *   d_out          [n][8] row-major   device
+ *   d_status       [n][8] int32 or NULL
+ * Asynchronous on `stream`. */
+int rimphony_batch_compute_device(rimphony_ctx *ctx, int dist_kind, size_t n,
+                                  const double *d_s, const double *d_theta,
+                                  const double *const *d_params, uint32_t coeff_mask,
+                                  double *d_out, int32_t *d_status, void *stream);
+
+/* Same with HOST buffers (copies in, computes, copies out, synchronises). */
+int rimphony_batch_compute(rimphony_ctx *ctx, int dist_kind, size_t n,
+                           const double *s, const double *theta,
+                           const double *const *params, uint32_t coeff_mask,
+                           double *out, int32_t *status);
+
+/* full_calculation() alone: the normalisation constant of each point
+ * (power_law.rs:93-103 etc.); NaN where the integral failed. */
+int rimphony_batch_norm_device(rimphony_ctx *ctx, int dist_kind, size_t n,
+                               const double *const *d_params, double *d_norm, void *stream);
+
+/* leung-bessel seam (leung-bessel/src/lib.rs:36-42), batched:
+ * d_j[i] = pkgw_bessel_j(d_n[i], d_x[i]), d_dj[i] = pkgw_bessel_dj(d_n[i], d_x[i]);
+ * either output may be NULL. */
+int rimphony_bessel_batch_device(rimphony_ctx *ctx, size_t count, const double *d_n, const double *d_x,
+                                 double *d_j, double *d_dj, void *stream);
+
+/* Diagnostic seam: FullSynchrotronCalculator::diagnostic_symphony_gamma_integrand
+ * (lib.rs:278-285), batched over (n, gamma) pairs for ONE parameter point given
+ * as host scalars.  params: host array of the kind's parameters. */
+int rimphony_gamma_integrand_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params,
+                                          int coeff, int stokes, double s, double theta,
+                                          size_t count, const double *d_n, const double *d_gamma,
+                                          double *d_out, void *stream);
+
+/* Diagnostic seam: diagnostic_symphony_gamma_integral (lib.rs:266-272), batched
+ * over orders n for one parameter point; negative_lobe selects the Stokes-V lobe. */
+int rimphony_gamma_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params,
+                                         int coeff, int stokes, int negative_lobe, double s, double theta,
+                                         size_t count, const double *d_n, double *d_out, void *stream);
+
+/* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
+ * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
+ *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1
+ *   family 2: x^2 * (p0 + x * p1)                  family 3: 1 / sqrt(|x - p0| + p1)
+ * Arrays of `count` problems; outputs result, abserr, status, size. */
+int rimphony_qag_selftest_device(rimphony_ctx *ctx, size_t count, const int32_t *d_family,
+                                 const double *d_p0, const double *d_p1, const double *d_a, const double *d_b,
+                                 double epsabs, double epsrel, int32_t limit,
+                                 double *d_result, double *d_abserr, int32_t *d_qstatus, int32_t *d_size,
+                                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

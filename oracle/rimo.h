@@ -126,6 +126,12 @@ double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negati
 int rimo_batch(int kind, size_t n, const double *s, const double *theta, const double *const *params,
                uint32_t coeff_mask, double *out, rimo_counters *counters, int nthreads);
 
+int rimo_batch_norm(int kind, size_t n, const double *const *params, double *norm);
+
+/* QAG self-test on integrands built from + - * / sqrt only (see include/rimphony_hip.h) */
+int rimo_qag_selftest(int family, double p0, double p1, double a, double b, double epsabs, double epsrel,
+                      size_t limit, double *result, double *abserr, size_t *size_out);
+
 const char *rimo_build_flavour(void);
 
 #ifdef __cplusplus

@@ -183,6 +183,15 @@ static double n_integration(sym_state *st, double n_start, int *failed)
     return ans;
 }
 
+/* Rust `x as i64`: truncate toward zero, saturating, NaN -> 0 */
+static int64_t sat_i64(double x)
+{
+    if (!(x == x)) return 0;
+    if (x >= 9223372036854775807.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t) x;
+}
+
 static void sym_init(sym_state *st, const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c)
 {
     st->d = d;
@@ -206,8 +215,8 @@ double rimo_symphony(const rimo_dist *d, int coeff, int stokes, double s, double
     sym_init(&st, d, coeff, stokes, s, theta, c);
 
     const double n_minus = s * m_fabs(st.sin_observer_angle);
-    const int64_t n_lo = (int64_t) (n_minus + 1.);
-    const int64_t n_hi = (int64_t) (n_minus + 1. + N_MAX);
+    const int64_t n_lo = sat_i64(n_minus + 1.);
+    const int64_t n_hi = sat_i64(n_minus + 1. + N_MAX);
 
     for (int64_t n = n_lo; n < n_hi; n++) {
         st.negative_lobe = 0;
@@ -356,5 +365,43 @@ int rimo_batch(int kind, size_t n, const double *s, const double *theta, const d
         counters_add(&total, &local);
     }
     if (counters) *counters = total;
+    return 0;
+}
+
+/* ---- QAG self-test integrands (+ - * / sqrt only): same families as the
+ * rimphony_qag_selftest_device entry point of the product ------------------- */
+
+typedef struct { int family; double p0, p1; } selftest_ctx;
+
+static double selftest_integrand(double x, void *ctx)
+{
+    const selftest_ctx *c = (const selftest_ctx *) ctx;
+    switch (c->family) {
+    case 0: { const double u = (x - c->p0) * c->p1; return 1. / (1. + u * u); }
+    case 1: return m_sqrt(m_fabs(x - c->p0)) * c->p1;
+    case 2: return x * x * (c->p0 + x * c->p1);
+    default: return 1. / m_sqrt(m_fabs(x - c->p0) + c->p1);
+    }
+}
+
+int rimo_qag_selftest(int family, double p0, double p1, double a, double b, double epsabs, double epsrel,
+                      size_t limit, double *result, double *abserr, size_t *size_out)
+{
+    selftest_ctx c = { family, p0, p1 };
+    return rimo_qag_gk31(selftest_integrand, &c, a, b, epsabs, epsrel, limit, result, abserr, size_out, NULL);
+}
+
+/* full_calculation() alone, batched (for parity tests of the norm kernel) */
+int rimo_batch_norm(int kind, size_t n, const double *const *params, double *norm)
+{
+    static const int NPAR[4] = { 4, 1, 5, 4 };
+    if (kind < 0 || kind > 3) return -1;
+    for (size_t i = 0; i < n; i++) {
+        double par[RIMO_MAX_PARAMS];
+        rimo_dist d;
+        for (int k = 0; k < NPAR[kind]; k++) par[k] = params[k][i];
+        int st = rimo_dist_init(&d, kind, par);
+        norm[i] = st ? RIM_NAN : d.norm;
+    }
     return 0;
 }

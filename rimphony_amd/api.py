@@ -1,0 +1,292 @@
+"""Host-side mirror of rimphony's public API on top of the HIP C ABI.
+
+Reference surface being mirrored (same names, argument meaning and error
+behaviour; see src/lib.rs of pkgw/rimphony):
+
+  Stokes, Coefficient                               lib.rs:74-107
+  SynchrotronCalculator.compute_dimensionless       lib.rs:155-156
+                       .compute_cgs                 lib.rs:163-173
+                       .compute_all_dimensionless   lib.rs:178-191
+                       .compute_all_cgs             lib.rs:196-209
+  PowerLawDistribution(p).gamma_limits(..).full_calculation()          power_law.rs:71-111
+  ThermalJuettnerDistribution(T).full_calculation()                    thermal_juettner.rs:45-72
+  PitchyPowerLawDistribution(p, k).gamma_limits(..).full_calculation() pitchy_pl.rs:73-115
+  PitchyKappaDistribution(kappa, width, k).gamma_cutoff(..)...         pitchy_kappa.rs:70-125
+
+plus the batched compute() the north star adds: `compute_batch`.  PyTorch is
+used only as plumbing (device buffers, the current HIP stream).  Everything is
+evaluated by librimphony_hip.so on the GPU; there is no CPU path here.
+"""
+import ctypes
+import enum
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+
+# lib.rs:55-67
+PI = math.pi
+TWO_PI = 2.0 * math.pi
+MASS_ELECTRON = 9.1093826e-28
+SPEED_LIGHT = 2.99792458e10
+ELECTRON_CHARGE = 4.80320680e-10
+
+
+class Stokes(enum.IntEnum):
+    I = 0
+    Q = 1
+    V = 2
+
+
+class Coefficient(enum.IntEnum):
+    Emission = 0
+    Absorption = 1
+    Faraday = 2
+
+
+POWER_LAW, THERMAL_JUETTNER, PITCHY_PL, PITCHY_KAPPA = 0, 1, 2, 3
+NPARAMS = {POWER_LAW: 4, THERMAL_JUETTNER: 1, PITCHY_PL: 5, PITCHY_KAPPA: 4}
+
+# slot order of compute_all_dimensionless (lib.rs:176-177)
+SLOTS = [
+    (Coefficient.Emission, Stokes.I), (Coefficient.Absorption, Stokes.I),
+    (Coefficient.Emission, Stokes.Q), (Coefficient.Absorption, Stokes.Q),
+    (Coefficient.Emission, Stokes.V), (Coefficient.Absorption, Stokes.V),
+    (Coefficient.Faraday, Stokes.Q), (Coefficient.Faraday, Stokes.V),
+]
+SLOTS_ALL = 0xFF
+SLOTS_SYMPHONY = 0x3F
+
+
+def slot_of(coeff, stokes):
+    return SLOTS.index((Coefficient(coeff), Stokes(stokes)))
+
+
+class Context:
+    """Owns a rimphony_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = capi.load()
+        if not torch.cuda.is_available():
+            raise capi.RimphonyError("no HIP device visible: rimphony_amd has no CPU fallback")
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        capi.check(self.lib.rimphony_ctx_create(self.device, ctypes.byref(h)), "rimphony_ctx_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.rimphony_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------
+    def _dev(self):
+        return torch.device("cuda", self.device)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
+
+    def _as_dev(self, x):
+        t = torch.as_tensor(x, dtype=torch.float64)
+        return t.to(self._dev()).contiguous()
+
+    # -- batched compute() -------------------------------------------------------
+    def compute_batch_device(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False):
+        """s, theta: CUDA float64 tensors [n]; params: list of CUDA float64 tensors [n].
+        Returns (out [n, 8] CUDA tensor, status [n, 8] int32 CUDA tensor or None).
+        Asynchronous on the current stream."""
+        n = s.numel()
+        assert len(params) == NPARAMS[kind]
+        out = torch.empty((n, 8), dtype=torch.float64, device=self._dev())
+        status = torch.empty((n, 8), dtype=torch.int32, device=self._dev()) if want_status else None
+        pp = (ctypes.c_void_p * len(params))(*[ctypes.c_void_p(p.data_ptr()) for p in params])
+        capi.check(self.lib.rimphony_batch_compute_device(
+            self.handle, kind, n, ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(theta.data_ptr()), pp,
+            coeff_mask, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(status.data_ptr()) if want_status else None, self._stream()),
+            "rimphony_batch_compute_device")
+        return out, status
+
+    def compute_batch(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False):
+        """Host arrays in, numpy arrays out (synchronous)."""
+        ds, dth = self._as_dev(s), self._as_dev(theta)
+        dp = [self._as_dev(p) for p in params]
+        out, st = self.compute_batch_device(kind, ds, dth, dp, coeff_mask, want_status)
+        torch.cuda.synchronize(self._dev())
+        if want_status:
+            return out.cpu().numpy(), st.cpu().numpy()
+        return out.cpu().numpy()
+
+    def last_work(self):
+        w = capi.Work()
+        capi.check(self.lib.rimphony_last_work(self.handle, ctypes.byref(w)), "rimphony_last_work")
+        return {"samples": int(w.samples), "passes": int(w.passes), "inner_qags": int(w.inner_qags)}
+
+    def last_symphony_ms(self):
+        ms = ctypes.c_float()
+        capi.check(self.lib.rimphony_last_symphony_ms(self.handle, ctypes.byref(ms)), "rimphony_last_symphony_ms")
+        return float(ms.value)
+
+    def norm_batch(self, kind, params):
+        dp = [self._as_dev(p) for p in params]
+        n = dp[0].numel()
+        out = torch.empty(n, dtype=torch.float64, device=self._dev())
+        pp = (ctypes.c_void_p * len(dp))(*[ctypes.c_void_p(p.data_ptr()) for p in dp])
+        capi.check(self.lib.rimphony_batch_norm_device(self.handle, kind, n, pp, ctypes.c_void_p(out.data_ptr()),
+                                                       self._stream()), "rimphony_batch_norm_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
+    # -- unit seams ----------------------------------------------------------------
+    def bessel_batch(self, n, x):
+        dn, dx = self._as_dev(n), self._as_dev(x)
+        j = torch.empty_like(dn)
+        dj = torch.empty_like(dn)
+        capi.check(self.lib.rimphony_bessel_batch_device(
+            self.handle, dn.numel(), ctypes.c_void_p(dn.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
+            ctypes.c_void_p(j.data_ptr()), ctypes.c_void_p(dj.data_ptr()), self._stream()),
+            "rimphony_bessel_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return j.cpu().numpy(), dj.cpu().numpy()
+
+    def gamma_integrand_batch(self, kind, params, coeff, stokes, s, theta, n, gamma):
+        dn, dg = self._as_dev(n), self._as_dev(gamma)
+        out = torch.empty_like(dn)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_gamma_integrand_batch_device(
+            self.handle, kind, par, int(coeff), int(stokes), s, theta, dn.numel(),
+            ctypes.c_void_p(dn.data_ptr()), ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+            self._stream()), "rimphony_gamma_integrand_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
+    def gamma_integral_batch(self, kind, params, coeff, stokes, negative_lobe, s, theta, n):
+        dn = self._as_dev(n)
+        out = torch.empty_like(dn)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_gamma_integral_batch_device(
+            self.handle, kind, par, int(coeff), int(stokes), int(negative_lobe), s, theta, dn.numel(),
+            ctypes.c_void_p(dn.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()),
+            "rimphony_gamma_integral_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
+    def qag_selftest(self, family, p0, p1, a, b, epsabs, epsrel, limit):
+        fam = torch.as_tensor(family, dtype=torch.int32).to(self._dev()).contiguous()
+        d = [self._as_dev(v) for v in (p0, p1, a, b)]
+        n = fam.numel()
+        res = torch.empty(n, dtype=torch.float64, device=self._dev())
+        err = torch.empty(n, dtype=torch.float64, device=self._dev())
+        qst = torch.empty(n, dtype=torch.int32, device=self._dev())
+        size = torch.empty(n, dtype=torch.int32, device=self._dev())
+        capi.check(self.lib.rimphony_qag_selftest_device(
+            self.handle, n, ctypes.c_void_p(fam.data_ptr()), *[ctypes.c_void_p(v.data_ptr()) for v in d],
+            epsabs, epsrel, int(limit), ctypes.c_void_p(res.data_ptr()), ctypes.c_void_p(err.data_ptr()),
+            ctypes.c_void_p(qst.data_ptr()), ctypes.c_void_p(size.data_ptr()), self._stream()),
+            "rimphony_qag_selftest_device")
+        torch.cuda.synchronize(self._dev())
+        return res.cpu().numpy(), err.cpu().numpy(), qst.cpu().numpy(), size.cpu().numpy()
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---------------------------------------------------------------------------------
+# distribution builders + calculators, named as in the reference
+# ---------------------------------------------------------------------------------
+
+class FullSynchrotronCalculator:
+    """lib.rs:230-247.  One parameter point; every call is a 1-point batch."""
+
+    def __init__(self, kind, params, ctx=None):
+        self.kind = kind
+        self.params = [float(p) for p in params]
+        self.ctx = ctx or default_context()
+
+    def _run(self, s, theta, mask):
+        out = self.ctx.compute_batch(self.kind, [s], [theta], [[p] for p in self.params], mask)
+        return out[0]
+
+    def compute_dimensionless(self, coeff, stokes, s, theta):
+        coeff, stokes = Coefficient(coeff), Stokes(stokes)
+        if coeff == Coefficient.Faraday and stokes == Stokes.I:
+            return float("nan")          # lib.rs:239-240
+        k = slot_of(coeff, stokes)
+        return float(self._run(s, theta, 1 << k)[k])
+
+    def compute_cgs(self, coeff, stokes, nu, b, n_e, theta):
+        nu_c = ELECTRON_CHARGE * b / (TWO_PI * MASS_ELECTRON * SPEED_LIGHT)
+        val = self.compute_dimensionless(coeff, stokes, nu / nu_c, theta)
+        if Coefficient(coeff) == Coefficient.Emission:
+            return val * n_e * nu
+        return val * n_e / nu
+
+    def compute_all_dimensionless(self, s, theta):
+        return np.array(self._run(s, theta, SLOTS_ALL))
+
+    def compute_all_cgs(self, nu, b, n_e, theta):
+        nu_c = ELECTRON_CHARGE * b / (TWO_PI * MASS_ELECTRON * SPEED_LIGHT)
+        v = self.compute_all_dimensionless(nu / nu_c, theta)
+        scale = np.array([n_e * nu if c == Coefficient.Emission else n_e / nu for c, _ in SLOTS])
+        return v * scale
+
+
+class PowerLawDistribution:
+    def __init__(self, p):
+        self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff = float(p), 1.0, 1e12, 1e10
+
+    def gamma_limits(self, gamma_min, gamma_max, gamma_cutoff):
+        self.gamma_min, self.gamma_max, self.gamma_cutoff = float(gamma_min), float(gamma_max), float(gamma_cutoff)
+        return self
+
+    def full_calculation(self, ctx=None):
+        return FullSynchrotronCalculator(POWER_LAW, [self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
+
+
+class ThermalJuettnerDistribution:
+    def __init__(self, t):
+        self.t = float(t)
+
+    def full_calculation(self, ctx=None):
+        return FullSynchrotronCalculator(THERMAL_JUETTNER, [self.t], ctx)
+
+
+class PitchyPowerLawDistribution:
+    def __init__(self, p, k):
+        self.p, self.k = float(p), float(k)
+        self.gamma_min, self.gamma_max, self.gamma_cutoff = 1.0, 1e12, 1e10
+
+    def gamma_limits(self, gamma_min, gamma_max, gamma_cutoff):
+        self.gamma_min, self.gamma_max, self.gamma_cutoff = float(gamma_min), float(gamma_max), float(gamma_cutoff)
+        return self
+
+    def full_calculation(self, ctx=None):
+        return FullSynchrotronCalculator(
+            PITCHY_PL, [self.p, self.k, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
+
+
+class PitchyKappaDistribution:
+    def __init__(self, kappa, width, k):
+        self.kappa, self.width, self.k, self._gamma_cutoff = float(kappa), float(width), float(k), 1e10
+
+    def gamma_cutoff(self, gamma_cutoff):
+        self._gamma_cutoff = float(gamma_cutoff)
+        return self
+
+    def full_calculation(self, ctx=None):
+        return FullSynchrotronCalculator(PITCHY_KAPPA, [self.kappa, self.width, self.k, self._gamma_cutoff], ctx)

@@ -1,0 +1,83 @@
+"""ctypes binding of the C ABI declared in include/rimphony_hip.h.
+
+No CPU fallback: loading fails loudly if librimphony_hip.so is missing, and
+creating a context fails loudly if there is no GPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librimphony_hip.so")
+
+SYMBOLS = [
+    "rimphony_dist_nparams", "rimphony_ctx_create", "rimphony_ctx_destroy", "rimphony_strerror",
+    "rimphony_version", "rimphony_last_work", "rimphony_last_symphony_ms", "rimphony_batch_compute_device", "rimphony_batch_compute",
+    "rimphony_batch_norm_device", "rimphony_bessel_batch_device", "rimphony_gamma_integrand_batch_device",
+    "rimphony_gamma_integral_batch_device", "rimphony_qag_selftest_device",
+]
+
+
+class RimphonyError(RuntimeError):
+    pass
+
+
+class Work(ctypes.Structure):
+    _fields_ = [("samples", c_uint64), ("passes", c_uint64), ("inner_qags", c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Load librimphony_hip.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RimphonyError(
+            "librimphony_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    dp = POINTER(c_double)
+    lib.rimphony_dist_nparams.restype = c_int
+    lib.rimphony_dist_nparams.argtypes = [c_int]
+    lib.rimphony_ctx_create.restype = c_int
+    lib.rimphony_ctx_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.rimphony_ctx_destroy.restype = None
+    lib.rimphony_ctx_destroy.argtypes = [c_void_p]
+    lib.rimphony_strerror.restype = c_char_p
+    lib.rimphony_strerror.argtypes = [c_int]
+    lib.rimphony_version.restype = c_char_p
+    lib.rimphony_last_work.restype = c_int
+    lib.rimphony_last_work.argtypes = [c_void_p, POINTER(Work)]
+    lib.rimphony_last_symphony_ms.restype = c_int
+    lib.rimphony_last_symphony_ms.argtypes = [c_void_p, POINTER(ctypes.c_float)]
+    lib.rimphony_batch_compute_device.restype = c_int
+    lib.rimphony_batch_compute_device.argtypes = [c_void_p, c_int, c_size_t, c_void_p, c_void_p, POINTER(c_void_p),
+                                                  c_uint32, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_batch_compute.restype = c_int
+    lib.rimphony_batch_compute.argtypes = [c_void_p, c_int, c_size_t, dp, dp, POINTER(dp), c_uint32, dp,
+                                           POINTER(c_int32)]
+    lib.rimphony_batch_norm_device.restype = c_int
+    lib.rimphony_batch_norm_device.argtypes = [c_void_p, c_int, c_size_t, POINTER(c_void_p), c_void_p, c_void_p]
+    lib.rimphony_bessel_batch_device.restype = c_int
+    lib.rimphony_bessel_batch_device.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_gamma_integrand_batch_device.restype = c_int
+    lib.rimphony_gamma_integrand_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_int, c_double, c_double,
+                                                          c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_gamma_integral_batch_device.restype = c_int
+    lib.rimphony_gamma_integral_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_int, c_int, c_double, c_double,
+                                                         c_size_t, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_qag_selftest_device.restype = c_int
+    lib.rimphony_qag_selftest_device.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_double, c_double, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rimphony_strerror(rc).decode()
+        raise RimphonyError("%s failed: %s (code %d)" % (what, msg, rc))

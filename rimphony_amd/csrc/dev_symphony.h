@@ -1,0 +1,249 @@
+// dev_symphony.h -- per-sample device functions of the Symphony path:
+// the four distribution functions and gamma_integrand.
+//
+//   DistributionFunction::calc_f / calc_f_derivatives
+//       power_law.rs:36-62, thermal_juettner.rs:29-39, pitchy_pl.rs:32-64,
+//       pitchy_kappa.rs:38-62
+//   CalculationState::gamma_integrand      symphony.rs:398-479
+//
+// The reference reaches these through a GSL callback trampoline per sample
+// (gsl.rs:111-117); here they are inlined into the wavefront quadrature, one
+// sample per lane.  Operation order matches oracle/rimo_dist.c and
+// oracle/rimo_symphony.c exactly (bit-for-bit parity is tested).
+#ifndef RIM_DEV_SYMPHONY_H
+#define RIM_DEV_SYMPHONY_H
+
+#include "dev_bessel.h"
+
+namespace rim {
+
+enum { DIST_POWER_LAW = 0, DIST_THERMAL_JUETTNER = 1, DIST_PITCHY_PL = 2, DIST_PITCHY_KAPPA = 3 };
+enum { STOKES_I = 0, STOKES_Q = 1, STOKES_V = 2 };
+enum { COEFF_EMISSION = 0, COEFF_ABSORPTION = 1, COEFF_FARADAY = 2 };
+
+// Distribution parameters of one point (wave-uniform).  par[] follows the C ABI:
+//   power_law {p, gmin, gmax, gcut}; thermal {T}; pitchy_pl {p, k, gmin, gmax, gcut};
+//   pitchy_kappa {kappa, width, k, gcut}.
+struct DistParams {
+    double par[5];
+    double inv_gamma_cutoff;
+    double inv_kappa_width;
+    double neg_inverse_t;
+    double norm;
+};
+
+template <int KIND>
+RIM_DEV void dist_prepare(DistParams &d, double norm)
+{
+    d.inv_gamma_cutoff = 0.;
+    d.inv_kappa_width = 0.;
+    d.neg_inverse_t = 0.;
+    d.norm = norm;
+    if (KIND == DIST_POWER_LAW) d.inv_gamma_cutoff = 1. / d.par[3];
+    if (KIND == DIST_THERMAL_JUETTNER) d.neg_inverse_t = -1. / d.par[0];
+    if (KIND == DIST_PITCHY_PL) d.inv_gamma_cutoff = 1. / d.par[4];
+    if (KIND == DIST_PITCHY_KAPPA) {
+        d.inv_kappa_width = 1. / (d.par[0] * d.par[1]);
+        d.inv_gamma_cutoff = 1. / d.par[3];
+    }
+}
+
+template <int KIND>
+RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
+{
+    if (KIND == DIST_POWER_LAW) {
+        if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
+        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        return d.norm * rim_pow(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
+    } else if (KIND == DIST_THERMAL_JUETTNER) {
+        return d.norm * rim_exp(d.neg_inverse_t * gamma);
+    } else if (KIND == DIST_PITCHY_PL) {
+        if (gamma < d.par[2] || gamma > d.par[3]) return 0.;
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = rim_pow(sin_xi, d.par[1]);
+        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        const double gamma_term = rim_pow(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        return d.norm * pa_term * gamma_term / (gamma * gamma * beta);
+    } else {
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = rim_pow(sin_xi, d.par[2]);
+        const double gamma_term = rim_pow(1. + (gamma - 1.) * d.inv_kappa_width, -(d.par[0] + 1.)) *
+            rim_exp(-gamma * d.inv_gamma_cutoff);
+        return d.norm * pa_term * gamma_term;
+    }
+}
+
+template <int KIND>
+RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi, double &dfdg, double &dfdcx)
+{
+    if (KIND == DIST_POWER_LAW) {
+        if (gamma < d.par[1] || gamma > d.par[2]) { dfdg = 0.; dfdcx = 0.; return; }
+        const double p_plus_1 = d.par[0] + 1.;
+        const double g2_minus_1 = gamma * gamma - 1.;
+        dfdg = -d.norm * rim_pow(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
+            rim_exp(-gamma * d.inv_gamma_cutoff) *
+            (p_plus_1 / gamma + gamma / g2_minus_1 + d.inv_gamma_cutoff);
+        dfdcx = 0.;
+    } else if (KIND == DIST_THERMAL_JUETTNER) {
+        dfdg = d.norm * rim_exp(d.neg_inverse_t * gamma) * d.neg_inverse_t;
+        dfdcx = 0.;
+    } else if (KIND == DIST_PITCHY_PL) {
+        if (gamma < d.par[2] || gamma > d.par[3]) { dfdg = 0.; dfdcx = 0.; return; }
+        const double p = d.par[0], k = d.par[1];
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = rim_pow(sin_xi, k);
+        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        const double gamma_term = rim_pow(gamma, -p) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
+        dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
+        dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
+    } else {
+        const double kappa = d.par[0], width = d.par[1], k = d.par[2];
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = rim_pow(sin_xi, k);
+        const double gamma_term = rim_pow(1. + (gamma - 1.) * d.inv_kappa_width, -(kappa + 1.)) *
+            rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double f = d.norm * pa_term * gamma_term;
+        dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);
+        dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
+    }
+}
+
+// Observer/point data shared by all samples of a coefficient (wave-uniform).
+struct SymPoint {
+    double s, cos_th, sin_th;
+    int coeff, stokes;
+};
+
+// Order data for one gamma-integral: J_n and J_{n+1} at fixed n (wave-uniform).
+struct SymOrder {
+    double n;
+    bool small;         // integer n < 30: Miller recurrence instead of the Leung expansions
+    bool np1_small;     // n + 1 < 30
+    bool dj_nan;        // n >= 1e15 (bessel.c:382-388)
+    LeungOrder o0, o1;  // orders n and n + 1 (valid when >= 30)
+};
+
+RIM_DEV SymOrder sym_order(double n)
+{
+    SymOrder so;
+    so.n = n;
+    so.small = n < 30.;
+    so.np1_small = (n + 1.) < 30.;
+    so.dj_nan = n >= 1e15;
+    so.o0 = LeungOrder();
+    so.o1 = LeungOrder();
+    if (!so.small) so.o0 = leung_order(n);
+    if (!so.np1_small) so.o1 = leung_order(n + 1.);
+    return so;
+}
+
+RIM_DEV LeungOrder select_order(bool second, const LeungOrder &a, const LeungOrder &b)
+{
+    LeungOrder o;
+    o.n = second ? b.n : a.n;
+    o.thr_lo = second ? b.thr_lo : a.thr_lo;
+    o.thr_hi = second ? b.thr_hi : a.thr_hi;
+    o.thr_plus_lo = second ? b.thr_plus_lo : a.thr_plus_lo;
+    o.ninv = second ? b.ninv : a.ninv;
+    o.np1 = second ? b.np1 : a.np1;
+    o.vsum2 = second ? b.vsum2 : a.vsum2;
+    o.lgam = second ? b.lgam : a.lgam;
+    o.small_eps_const = second ? b.small_eps_const : a.small_eps_const;
+    o.big_n = second ? b.big_n : a.big_n;
+    return o;
+}
+
+// J_n(z) and J'_n(z) as the reference's pkgw_bessel_j / pkgw_bessel_dj pair would
+// return them.  The two Leung evaluations (orders n and n+1) run through one
+// loop body so the expansions are inlined once.
+RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &djn)
+{
+    const double n = so.n;
+    double jv0 = 0., jv1 = 0.;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int w = 0; w < 2; w++) {
+        const bool second = w != 0;
+        const bool is_small = second ? so.np1_small : so.small;
+        if (!is_small) {
+            const LeungOrder o = select_order(second, so.o0, so.o1);
+            const double v = leung_j(o, z);
+            if (second) jv1 = v; else jv0 = v;
+        }
+    }
+    if (so.small) {
+        // the reference returns NaN for non-integer n < 30 (bessel.c:327-331)
+        const int n_int = (int) n;
+        if (!(n >= 0 && z >= 0) || (double) n_int != n) {
+            jv0 = RIM_NAN; jv1 = RIM_NAN;
+        } else {
+            double a, b;
+            jn_int_pair(n_int, z, &a, &b);
+            jv0 = a;
+            if (so.np1_small) jv1 = b;
+        }
+    }
+    jn = jv0;
+    const double jnp1 = jv1;
+    if (so.dj_nan) { djn = RIM_NAN; return; }
+    if (z == 0.) {
+        if (n >= 2.) djn = 0.;
+        else if (n == 0.) djn = -jnp1;
+        else djn = n * jn / RIM_DBL_MIN - jnp1;
+        return;
+    }
+    djn = n * jn / z - jnp1;
+}
+
+template <int KIND>
+RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const SymOrder &so, double gamma)
+{
+    const double s = pt.s, n = so.n;
+    const double cos_th = pt.cos_th, sin_th = pt.sin_th;
+
+    const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+    const double cos_xi = (s * gamma - n) / (s * gamma * beta * cos_th);
+    const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+    const double m = (cos_th - beta * cos_xi) / sin_th;
+    const double big_n = beta * sin_xi;
+
+    double gamma_sin_xi;
+    if (beta < 0.1) {
+        gamma_sin_xi = gamma * sin_xi;
+    } else {
+        const double bc = beta * cos_th;
+        const double beta2_costh2 = bc * bc;
+        const double s_on_r = 2. * n / (s * (beta2_costh2 - 1.));
+        const double r = 1. - 1. / beta2_costh2;
+        gamma_sin_xi = rim_sqrt(r * (gamma * (gamma + s_on_r)) - (n * n / (s * s * beta2_costh2)));
+    }
+
+    const double z = s * beta * sin_th * gamma_sin_xi;
+
+    double jn, djn;
+    sym_bessel_pair(so, z, jn, djn);
+    const double mj = m * jn;
+    const double njp = big_n * djn;
+
+    double pol_term;
+    if (pt.stokes == STOKES_I) pol_term = mj * mj + njp * njp;
+    else if (pt.stokes == STOKES_Q) pol_term = mj * mj - njp * njp;
+    else pol_term = 2. * mj * njp;
+
+    double f_term;
+    if (pt.coeff == COEFF_EMISSION) {
+        f_term = calc_f<KIND>(d, gamma, cos_xi);
+    } else {
+        double dfdg, dfdcx;
+        calc_f_derivatives<KIND>(d, gamma, cos_xi, dfdg, dfdcx);
+        const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
+        f_term = dfdg + dfdcx_factor * dfdcx;
+    }
+
+    return gamma * gamma * pol_term * f_term;
+}
+
+}  // namespace rim
+#endif

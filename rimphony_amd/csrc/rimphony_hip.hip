@@ -1,0 +1,702 @@
+// rimphony_hip.hip -- kernels and C ABI of librimphony_hip.so (gfx950 only).
+//
+// Kernels (one 64-lane wavefront per workgroup; each wave owns its LDS):
+//   norm_kernel<KIND>      full_calculation(): per-point normalisation integral
+//   symphony_kernel<KIND>  (point, coefficient) tasks pulled from an atomic queue
+//   bessel_kernel, integrand_kernel, gamma_integral_kernel, qag_selftest_kernel
+//                          unit seams used by the parity tests
+//
+// Launch geometry: a persistent grid of RIM_WAVES_PER_CU x 256 single-wave
+// workgroups; per-task cost spans orders of magnitude, so
+// tasks are handed out dynamically, one atomicAdd per task.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rimphony_hip.h"
+#include "symphony_wave.h"
+
+using namespace rim;
+
+#define CAP_INNER 128
+#define CAP_OUTER 128
+#define CAP_NORM 256
+
+// ------------------------------------------------------------------------------
+// normalisation integrands (power_law.rs:95-96, pitchy_kappa.rs:100-104; the
+// thermal one is the substituted form documented in oracle/rimo_dist.c)
+// ------------------------------------------------------------------------------
+
+template <int KIND>
+__device__ inline double norm_integrand(const DistParams &d, double g)
+{
+    if (KIND == DIST_POWER_LAW || KIND == DIST_PITCHY_PL) {
+        return rim_pow(g, -d.par[0]) * rim_exp(-g * d.inv_gamma_cutoff);
+    } else if (KIND == DIST_PITCHY_KAPPA) {
+        return g * rim_sqrt(g * g - 1.) *
+            rim_pow(1. + (g - 1.) * d.inv_kappa_width, -(d.par[0] + 1.)) *
+            rim_exp(-g * d.inv_gamma_cutoff);
+    } else {
+        const double u = g;
+        const double u2 = u * u;
+        const double gg = 1. + u2;
+        return gg * (u * rim_sqrt(u2 + 2.)) * rim_exp(d.neg_inverse_t * gg) * (2. * u);
+    }
+}
+
+__device__ inline double hyperg_2F1_at_1(double a, double b, double c)
+{
+    const double lc = rim_lgamma_pos(c);
+    const double lcab = rim_lgamma_pos(c - a - b);
+    const double lca = rim_lgamma_pos(c - a);
+    const double lcb = rim_lgamma_pos(c - b);
+    return rim_exp(lc + lcab - lca - lcb);
+}
+
+struct ParamPtrs { const double *p[5]; };
+
+template <int KIND>
+__device__ inline void load_params(const ParamPtrs &pp, size_t i, DistParams &d)
+{
+    constexpr int NP = (KIND == DIST_POWER_LAW) ? 4 : (KIND == DIST_THERMAL_JUETTNER) ? 1 : (KIND == DIST_PITCHY_PL) ? 5 : 4;
+#pragma unroll
+    for (int k = 0; k < 5; k++) d.par[k] = (k < NP) ? pp.p[k][i] : 0.;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double *norm, unsigned long long *queue)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_store[RIM_ISTORE_DOUBLES(CAP_NORM)];
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore st = istore_carve(s_store, CAP_NORM);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+
+    for (;;) {
+        unsigned long long t = 0;
+        if (g.lane == 0) t = atomicAdd(queue, 1ull);
+        t = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
+            (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
+        if (t >= n) break;
+        const size_t i = (size_t) t;
+
+        DistParams d;
+        load_params<KIND>(pp, i, d);
+        dist_prepare<KIND>(d, RIM_NAN);
+
+        double lo, hi, epsrel, pa = 1.;
+        if (KIND == DIST_POWER_LAW) { lo = d.par[1]; hi = d.par[2]; epsrel = 1e-8; }
+        else if (KIND == DIST_PITCHY_PL) { lo = d.par[2]; hi = d.par[3]; epsrel = 1e-8; pa = hyperg_2F1_at_1(0.5, -0.5 * d.par[1], 1.5); }
+        else if (KIND == DIST_PITCHY_KAPPA) {
+            const double g_cut = 1. / d.inv_gamma_cutoff;
+            lo = 1.; hi = 1e3 * g_cut; epsrel = 1e-8; pa = hyperg_2F1_at_1(0.5, -0.5 * d.par[2], 1.5);
+        } else { lo = 0.; hi = rim_sqrt(60. * d.par[0] + 4.); epsrel = 1e-10; }
+
+        auto f = [&](double x, bool active) -> double { return active ? norm_integrand<KIND>(d, x) : 0.; };
+        QagState q;
+        wave_qag(f, g, st, lo, hi, 0., epsrel, 1000, q, &s_qpark);
+        double v = RIM_NAN;
+        if (q.status == QAG_SUCCESS) {
+            if (KIND == DIST_PITCHY_PL || KIND == DIST_PITCHY_KAPPA) v = 1. / (2. * RIM_TWO_PI * pa * q.result);
+            else v = 1. / (2. * RIM_TWO_PI * q.result);
+        }
+        if (g.lane == 0) norm[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// symphony
+// ------------------------------------------------------------------------------
+
+struct SymArgs {
+    ParamPtrs pp;
+    const double *s, *theta, *norm;
+    double *out;
+    int32_t *status;
+    size_t n;
+    int nslots;
+    int slot[8];
+    unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
+};
+
+__constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
+__constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
+
+__device__ inline unsigned long long wave_next_task(unsigned long long *queue, int lane)
+{
+    unsigned long long t = 0;
+    if (lane == 0) t = atomicAdd(queue, 1ull);
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
+           (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
+    __shared__ TaskState s_park;
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore inner = istore_carve(s_inner, CAP_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
+    for (;;) {
+        const unsigned long long t = wave_next_task(a.queue, g.lane);
+        if (t >= ntasks) break;
+        // slot-major within a point: consecutive tasks share the point's inputs in L2
+        const size_t i = (size_t) (t / (unsigned) a.nslots);
+        const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
+
+        SymPoint pt;
+        pt.s = uni(a.s[i]);
+        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
+        pt.sin_th = uni(pt.sin_th);
+        pt.cos_th = uni(pt.cos_th);
+        pt.coeff = uni(c_slot_coeff[slot]);
+        pt.stokes = uni(c_slot_stokes[slot]);
+
+        DistParams d;
+        load_params<KIND>(a.pp, i, d);
+        const double norm = uni(a.norm[i]);
+        dist_prepare<KIND>(d, norm);
+#pragma unroll
+        for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
+        d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
+        d.inv_kappa_width = uni(d.inv_kappa_width);
+        d.neg_inverse_t = uni(d.neg_inverse_t);
+
+        double val;
+        int st = 0;
+        if (!(norm == norm)) {
+            val = RIM_NAN;
+            st = ST_NORM_FAIL | ST_NONFINITE;
+        } else {
+            val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
+        }
+        if (g.lane == 0) {
+            a.out[i * 8 + slot] = val;
+            if (a.status) a.status[i * 8 + slot] = st;
+        }
+    }
+
+    __syncthreads();
+    if (g.lane == 0) {
+        atomicAdd(a.queue + 1, s_qpark.ctr.samples);
+        atomicAdd(a.queue + 2, s_qpark.ctr.steps);
+        atomicAdd(a.queue + 3, s_qpark.ctr.inner_qags);
+    }
+}
+
+// fills the slots that were not selected (or not yet available) with NaN
+__global__ void fill_unselected_kernel(double *out, int32_t *status, size_t n, uint32_t computed_mask)
+{
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 8) return;
+    const int slot = (int) (idx & 7);
+    if (!(computed_mask & (1u << slot))) {
+        out[idx] = RIM_NAN;
+        if (status) status[idx] = ST_NONFINITE | RIMPHONY_ST_NOT_COMPUTED;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// unit seams
+// ------------------------------------------------------------------------------
+
+__global__ void bessel_kernel(size_t count, const double *n, const double *x, double *j, double *dj)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (j) j[i] = bessel_j(n[i], x[i]);
+    if (dj) dj[i] = bessel_dj(n[i], x[i]);
+}
+
+struct PointArgs {
+    double par[5];
+    double s, theta;
+    int coeff, stokes, negative_lobe;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const double *norm_ptr, size_t count,
+                                                            const double *nvals, double *out)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore inner = istore_carve(s_inner, CAP_INNER);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    SymPoint pt;
+    pt.s = pa.s;
+    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
+    pt.coeff = pa.coeff;
+    pt.stokes = pa.stokes;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const double n = nvals[i];
+        const SymOrder so = sym_order(n);
+        const GammaLimits L = gamma_limits(pt, n, pa.negative_lobe);
+        auto f = [&](double x, bool active) -> double { return active ? gamma_integrand<KIND>(pt, d, so, x) : 0.; };
+        QagState q;
+        wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, q, &s_qpark);
+        if (g.lane == 0) out[i] = (q.status == QAG_SUCCESS) ? q.result : RIM_NAN;
+    }
+}
+
+__device__ inline double selftest_integrand(int family, double p0, double p1, double x)
+{
+    switch (family) {
+    case 0: { const double u = (x - p0) * p1; return 1. / (1. + u * u); }
+    case 1: return rim_sqrt(rim_fabs(x - p0)) * p1;
+    case 2: return x * x * (p0 + x * p1);
+    default: return 1. / rim_sqrt(rim_fabs(x - p0) + p1);
+    }
+}
+
+__global__ __launch_bounds__(64) void qag_selftest_kernel(size_t count, const int32_t *family, const double *p0,
+                                                          const double *p1, const double *a, const double *b,
+                                                          double epsabs, double epsrel, int limit,
+                                                          double *result, double *abserr, int32_t *qstatus, int32_t *size)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_store[RIM_ISTORE_DOUBLES(CAP_NORM)];
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore st = istore_carve(s_store, CAP_NORM);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const int fam = family[i];
+        const double q0 = p0[i], q1 = p1[i];
+        auto f = [&](double x, bool active) -> double { return active ? selftest_integrand(fam, q0, q1, x) : 0.; };
+        QagState q;
+        wave_qag(f, g, st, a[i], b[i], epsabs, epsrel, limit, q, &s_qpark);
+        if (g.lane == 0) {
+            result[i] = q.result;
+            abserr[i] = q.abserr;
+            qstatus[i] = q.status;
+            size[i] = q.size;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------
+
+struct rimphony_ctx {
+    int device;
+    int n_cu;
+    unsigned long long *d_queue;   // 4 words
+    double *d_norm;
+    size_t norm_cap;
+    // staging for the host-buffer entry point
+    double *d_in;
+    size_t in_cap;
+    double *d_out;
+    int32_t *d_status;
+    size_t out_cap;
+    // HIP events bracketing the most recent symphony_kernel launch
+    hipEvent_t ev_start, ev_stop;
+    int ev_valid;
+};
+
+#define HIP_TRY(expr)                                                            \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            fprintf(stderr, "rimphony_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            return RIMPHONY_EHIP;                                                \
+        }                                                                        \
+    } while (0)
+
+static const int NPARAMS[4] = { 4, 1, 5, 4 };
+
+extern "C" int rimphony_dist_nparams(int kind)
+{
+    if (kind < 0 || kind > 3) return RIMPHONY_EINVAL;
+    return NPARAMS[kind];
+}
+
+extern "C" const char *rimphony_strerror(int code)
+{
+    switch (code) {
+    case RIMPHONY_OK: return "success";
+    case RIMPHONY_EINVAL: return "invalid argument";
+    case RIMPHONY_EHIP: return "HIP runtime error";
+    case RIMPHONY_ENOMEM: return "out of memory";
+    case RIMPHONY_ENODEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *rimphony_version(void) { return "rimphony_hip 0.1 (gfx950)"; }
+
+extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
+{
+    if (!out) return RIMPHONY_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RIMPHONY_ENODEVICE;
+    if (device < 0 || device >= ndev) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    rimphony_ctx *c = new (std::nothrow) rimphony_ctx();
+    if (!c) return RIMPHONY_ENOMEM;
+    memset(c, 0, sizeof *c);
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(&c->d_queue, 4 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        (void) hipFree(c->d_queue);
+        delete c;
+        return RIMPHONY_EHIP;
+    }
+    *out = c;
+    return RIMPHONY_OK;
+}
+
+extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
+{
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    if (c->d_queue) (void) hipFree(c->d_queue);
+    if (c->d_norm) (void) hipFree(c->d_norm);
+    if (c->d_in) (void) hipFree(c->d_in);
+    if (c->d_out) (void) hipFree(c->d_out);
+    if (c->d_status) (void) hipFree(c->d_status);
+    (void) hipEventDestroy(c->ev_start);
+    (void) hipEventDestroy(c->ev_stop);
+    delete c;
+}
+
+static int ensure_norm(rimphony_ctx *c, size_t n)
+{
+    if (c->norm_cap >= n) return RIMPHONY_OK;
+    if (c->d_norm) (void) hipFree(c->d_norm);
+    c->d_norm = nullptr;
+    c->norm_cap = 0;
+    if (hipMalloc(&c->d_norm, n * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+    c->norm_cap = n;
+    return RIMPHONY_OK;
+}
+
+// persistent grid: enough single-wave workgroups to fill every SIMD several times over
+static unsigned persistent_grid(const rimphony_ctx *c, unsigned long long ntasks, int waves_per_cu)
+{
+    unsigned long long g = (unsigned long long) c->n_cu * (unsigned) waves_per_cu;
+    if (g > ntasks) g = ntasks;
+    if (g < 1) g = 1;
+    return (unsigned) g;
+}
+
+template <int KIND>
+static int launch_norm(rimphony_ctx *c, size_t n, const ParamPtrs &pp, double *d_norm, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), st));
+    const unsigned grid = persistent_grid(c, n, 16);
+    hipLaunchKernelGGL(norm_kernel<KIND>, dim3(grid), dim3(64), 0, st, pp, n, d_norm, c->d_queue);
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+static int make_param_ptrs(int kind, const double *const *d_params, ParamPtrs &pp)
+{
+    if (kind < 0 || kind > 3 || !d_params) return RIMPHONY_EINVAL;
+    for (int k = 0; k < 5; k++) pp.p[k] = nullptr;
+    for (int k = 0; k < NPARAMS[kind]; k++) {
+        if (!d_params[k]) return RIMPHONY_EINVAL;
+        pp.p[k] = d_params[k];
+    }
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_batch_norm_device(rimphony_ctx *c, int kind, size_t n, const double *const *d_params,
+                                          double *d_norm, void *stream)
+{
+    if (!c || !d_norm) return RIMPHONY_EINVAL;
+    ParamPtrs pp;
+    int rc = make_param_ptrs(kind, d_params, pp);
+    if (rc) return rc;
+    if (n == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    switch (kind) {
+    case 0: return launch_norm<0>(c, n, pp, d_norm, st);
+    case 1: return launch_norm<1>(c, n, pp, d_norm, st);
+    case 2: return launch_norm<2>(c, n, pp, d_norm, st);
+    default: return launch_norm<3>(c, n, pp, d_norm, st);
+    }
+}
+
+template <int KIND>
+static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
+{
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
+    const unsigned grid = persistent_grid(c, ntasks, 16);
+    HIP_TRY(hipEventRecord(c->ev_start, st));
+    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_stop, st));
+    c->ev_valid = 1;
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n,
+                                             const double *d_s, const double *d_theta,
+                                             const double *const *d_params, uint32_t coeff_mask,
+                                             double *d_out, int32_t *d_status, void *stream)
+{
+    if (!c || !d_out) return RIMPHONY_EINVAL;
+    if (n && (!d_s || !d_theta)) return RIMPHONY_EINVAL;
+    ParamPtrs pp;
+    int rc = make_param_ptrs(kind, d_params, pp);
+    if (rc) return rc;
+    if (n == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+
+    rc = ensure_norm(c, n);
+    if (rc) return rc;
+
+    // full_calculation()
+    switch (kind) {
+    case 0: rc = launch_norm<0>(c, n, pp, c->d_norm, st); break;
+    case 1: rc = launch_norm<1>(c, n, pp, c->d_norm, st); break;
+    case 2: rc = launch_norm<2>(c, n, pp, c->d_norm, st); break;
+    default: rc = launch_norm<3>(c, n, pp, c->d_norm, st); break;
+    }
+    if (rc) return rc;
+
+    SymArgs a;
+    a.pp = pp;
+    a.s = d_s;
+    a.theta = d_theta;
+    a.norm = c->d_norm;
+    a.out = d_out;
+    a.status = d_status;
+    a.n = n;
+    a.queue = c->d_queue;
+    a.nslots = 0;
+    uint32_t computed = 0;
+    for (int k = 0; k < 6; k++)     // symphony slots: j/alpha x I,Q,V
+        if (coeff_mask & (1u << k)) { a.slot[a.nslots++] = k; computed |= 1u << k; }
+    for (int k = a.nslots; k < 8; k++) a.slot[k] = 0;
+
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 4 * sizeof(unsigned long long), st));
+    {
+        const size_t total = n * 8;
+        hipLaunchKernelGGL(fill_unselected_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
+                           d_out, d_status, n, computed);
+        HIP_TRY(hipGetLastError());
+    }
+    if (a.nslots > 0) {
+        switch (kind) {
+        case 0: rc = launch_symphony<0>(c, a, st); break;
+        case 1: rc = launch_symphony<1>(c, a, st); break;
+        case 2: rc = launch_symphony<2>(c, a, st); break;
+        default: rc = launch_symphony<3>(c, a, st); break;
+        }
+        if (rc) return rc;
+    }
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_last_symphony_ms(rimphony_ctx *c, float *ms)
+{
+    if (!c || !ms) return RIMPHONY_EINVAL;
+    if (!c->ev_valid) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
+{
+    if (!c || !out) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpy(h, c->d_queue, sizeof h, hipMemcpyDeviceToHost));
+    out->samples = h[1];
+    out->passes = h[2];
+    out->inner_qags = h[3];
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_batch_compute(rimphony_ctx *c, int kind, size_t n,
+                                      const double *s, const double *theta, const double *const *params,
+                                      uint32_t coeff_mask, double *out, int32_t *status)
+{
+    if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;
+    if (!s || !theta) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const int np = NPARAMS[kind];
+    const size_t need_in = n * (size_t) (2 + np);
+    if (c->in_cap < need_in) {
+        if (c->d_in) (void) hipFree(c->d_in);
+        c->d_in = nullptr; c->in_cap = 0;
+        if (hipMalloc(&c->d_in, need_in * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+        c->in_cap = need_in;
+    }
+    if (c->out_cap < n) {
+        if (c->d_out) (void) hipFree(c->d_out);
+        if (c->d_status) (void) hipFree(c->d_status);
+        c->d_out = nullptr; c->d_status = nullptr; c->out_cap = 0;
+        if (hipMalloc(&c->d_out, n * 8 * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+        if (hipMalloc(&c->d_status, n * 8 * sizeof(int32_t)) != hipSuccess) return RIMPHONY_ENOMEM;
+        c->out_cap = n;
+    }
+    HIP_TRY(hipMemcpy(c->d_in, s, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_in + n, theta, n * sizeof(double), hipMemcpyHostToDevice));
+    const double *dp[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    for (int k = 0; k < np; k++) {
+        if (!params[k]) return RIMPHONY_EINVAL;
+        HIP_TRY(hipMemcpy(c->d_in + (size_t) (2 + k) * n, params[k], n * sizeof(double), hipMemcpyHostToDevice));
+        dp[k] = c->d_in + (size_t) (2 + k) * n;
+    }
+    int rc = rimphony_batch_compute_device(c, kind, n, c->d_in, c->d_in + n, dp, coeff_mask, c->d_out, c->d_status, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->d_out, n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, c->d_status, n * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_bessel_batch_device(rimphony_ctx *c, size_t count, const double *d_n, const double *d_x,
+                                            double *d_j, double *d_dj, void *stream)
+{
+    if (!c || (count && (!d_n || !d_x))) return RIMPHONY_EINVAL;
+    if (count == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(bessel_kernel, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       count, d_n, d_x, d_j, d_dj);
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+static int fill_point_args(int kind, const double *params, int coeff, int stokes, int negative_lobe,
+                           double s, double theta, PointArgs &pa)
+{
+    if (kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
+    if (coeff < 0 || coeff > 1 || stokes < 0 || stokes > 2) return RIMPHONY_EINVAL;
+    for (int k = 0; k < 5; k++) pa.par[k] = (k < NPARAMS[kind]) ? params[k] : 0.;
+    pa.s = s; pa.theta = theta; pa.coeff = coeff; pa.stokes = stokes; pa.negative_lobe = negative_lobe;
+    return RIMPHONY_OK;
+}
+
+// normalisation of a single host-described point -> c->d_norm[0]
+static int single_point_norm(rimphony_ctx *c, int kind, const double *params, hipStream_t st)
+{
+    int rc = ensure_norm(c, 8);
+    if (rc) return rc;
+    // params live in d_norm[1..5] as five 1-element SoA arrays
+    double h[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int k = 0; k < NPARAMS[kind]; k++) h[1 + k] = params[k];
+    HIP_TRY(hipMemcpyAsync(c->d_norm, h, sizeof h, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // h is a stack buffer
+    ParamPtrs pp;
+    for (int k = 0; k < 5; k++) pp.p[k] = c->d_norm + 1 + k;
+    switch (kind) {
+    case 0: return launch_norm<0>(c, 1, pp, c->d_norm, st);
+    case 1: return launch_norm<1>(c, 1, pp, c->d_norm, st);
+    case 2: return launch_norm<2>(c, 1, pp, c->d_norm, st);
+    default: return launch_norm<3>(c, 1, pp, c->d_norm, st);
+    }
+}
+
+template <int KIND>
+__global__ void integrand_kernel_n(PointArgs pa, const double *norm_ptr, size_t count, const double *n,
+                                   const double *gamma, double *out)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    SymPoint pt;
+    pt.s = pa.s;
+    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
+    pt.coeff = pa.coeff;
+    pt.stokes = pa.stokes;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    const SymOrder so = sym_order(n[i]);
+    out[i] = gamma_integrand<KIND>(pt, d, so, gamma[i]);
+}
+
+extern "C" int rimphony_gamma_integrand_batch_device(rimphony_ctx *c, int kind, const double *params,
+                                                     int coeff, int stokes, double s, double theta,
+                                                     size_t count, const double *d_n, const double *d_gamma,
+                                                     double *d_out, void *stream)
+{
+    if (!c || (count && (!d_n || !d_gamma || !d_out))) return RIMPHONY_EINVAL;
+    PointArgs pa;
+    int rc = fill_point_args(kind, params, coeff, stokes, 0, s, theta, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    rc = single_point_norm(c, kind, params, st);
+    if (rc) return rc;
+    const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(integrand_kernel_n<0>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    case 1: hipLaunchKernelGGL(integrand_kernel_n<1>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    case 2: hipLaunchKernelGGL(integrand_kernel_n<2>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    default: hipLaunchKernelGGL(integrand_kernel_n<3>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
+                                                    int coeff, int stokes, int negative_lobe, double s, double theta,
+                                                    size_t count, const double *d_n, double *d_out, void *stream)
+{
+    if (!c || (count && (!d_n || !d_out))) return RIMPHONY_EINVAL;
+    PointArgs pa;
+    int rc = fill_point_args(kind, params, coeff, stokes, negative_lobe, s, theta, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    rc = single_point_norm(c, kind, params, st);
+    if (rc) return rc;
+    const unsigned grid = persistent_grid(c, count, 16);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(gamma_integral_kernel<0>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
+    case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
+    case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
+    default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_qag_selftest_device(rimphony_ctx *c, size_t count, const int32_t *d_family,
+                                            const double *d_p0, const double *d_p1, const double *d_a, const double *d_b,
+                                            double epsabs, double epsrel, int32_t limit,
+                                            double *d_result, double *d_abserr, int32_t *d_qstatus, int32_t *d_size,
+                                            void *stream)
+{
+    if (!c || (count && (!d_family || !d_p0 || !d_p1 || !d_a || !d_b || !d_result || !d_abserr || !d_qstatus || !d_size)))
+        return RIMPHONY_EINVAL;
+    if (limit < 1) return RIMPHONY_EINVAL;
+    if (count == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned grid = persistent_grid(c, count, 16);
+    hipLaunchKernelGGL(qag_selftest_kernel, dim3(grid), dim3(64), 0, (hipStream_t) stream, count, d_family, d_p0, d_p1,
+                       d_a, d_b, epsabs, epsrel, (int) limit, d_result, d_abserr, d_qstatus, d_size);
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}

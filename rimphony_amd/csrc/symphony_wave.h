@@ -1,0 +1,371 @@
+// symphony_wave.h -- one wavefront computes one Symphony coefficient.
+//
+//   CalculationState::compute   symphony.rs:66-187   (30 discrete harmonics + n tail, V in two lobes)
+//   n_integration               symphony.rs:196-295  (deriv_central probe, chunk growth, QAG over n)
+//   gamma_integral              symphony.rs:312-389  (limits, rel_width, QAG over gamma)
+//   gsl::deriv_central          gsl.rs:233-257 -> gsl_deriv_central (restated in oracle/rimo_quad.c)
+//
+// Control structure.  The reference nests callbacks: QAG(n) -> [per node]
+// QAG(gamma) -> [per node] integrand.  On the GPU the innermost level is the
+// only place with lane parallelism (31 or 62 samples per pass), so the wave
+// runs the gamma-integrals one after another and everything above them is
+// wave-uniform bookkeeping.  To keep a SINGLE inlined copy of the expensive
+// code (integrand + inner QAG) in the kernel, the three callers of
+// gamma_integral -- the discrete harmonics, the finite-difference probe and the
+// outer GK31 rule -- are written as phases of one state machine: each phase
+// posts a batch of up to 62 (n, lobe) requests, one per lane, the common loop
+// evaluates them, and the phase's continuation consumes the 62 results.
+//
+// Every arithmetic step is in the same order as oracle/rimo_symphony.c.
+#ifndef RIM_SYMPHONY_WAVE_H
+#define RIM_SYMPHONY_WAVE_H
+
+#include "wave_qag.h"
+#include "dev_symphony.h"
+
+namespace rim {
+
+#define RIM_TWO_PI (2. * RIM_PI)
+#define RIM_MASS_ELECTRON 9.1093826e-28
+#define RIM_SPEED_LIGHT 2.99792458e10
+#define RIM_ELECTRON_CHARGE 4.80320680e-10
+#define RIM_MAX_CHUNKS 4096
+
+// status bits reported per coefficient
+enum {
+    ST_OK = 0,
+    ST_INNER_FAIL = 1,     // some gamma-integral returned an error (-> NaN sample upstream)
+    ST_OUTER_FAIL = 2,     // an n-chunk QAG failed
+    ST_CHUNK_CAP = 4,      // RIM_MAX_CHUNKS exceeded
+    ST_STORE_FULL = 8,     // LDS subinterval store exhausted
+    ST_NONFINITE = 16,     // result is NaN
+    ST_NORM_FAIL = 32      // distribution normalisation failed
+};
+
+// Rust `x as i64`: truncate toward zero, saturating, NaN -> 0
+__device__ inline long long sat_i64(double x)
+{
+    if (!(x == x)) return 0;
+    if (x >= 9223372036854775807.0) return 9223372036854775807LL;
+    if (x <= -9223372036854775808.0) return (-9223372036854775807LL - 1);
+    return (long long) x;
+}
+
+// gamma_integral (symphony.rs:312-389): limits for order n and lobe.
+struct GammaLimits { double g0, g1; };
+
+__device__ inline GammaLimits gamma_limits(const SymPoint &pt, double n, int negative_lobe)
+{
+    const double s = pt.s;
+    const double acos_th = rim_fabs(pt.cos_th);
+    const double sin2 = pt.sin_th * pt.sin_th;
+    const double nos = n / s;
+    const double root = rim_sqrt(nos * nos - sin2);
+    const double gamma_minus = (nos - acos_th * root) / sin2;
+    const double gamma_plus = (nos + acos_th * root) / sin2;
+    const double gamma_peak = 0.5 * (gamma_plus + gamma_minus);
+    const double rel_width = (s < 1e6) ? 1. : rim_exp(-0.27 * rim_log(n) - 0.1);
+    const double gamma_minus_high = gamma_peak - (gamma_peak - gamma_minus) * rel_width;
+    const double gamma_plus_high = gamma_peak - (gamma_peak - gamma_plus) * rel_width;
+    GammaLimits L;
+    if (pt.stokes == STOKES_V) {
+        if (!negative_lobe) { L.g0 = gamma_peak; L.g1 = gamma_plus_high; }
+        else { L.g0 = gamma_minus_high; L.g1 = gamma_peak; }
+    } else {
+        L.g0 = gamma_minus_high;
+        L.g1 = gamma_plus_high;
+    }
+    return L;
+}
+
+enum Phase { PH_DISCRETE = 0, PH_DERIV1, PH_DERIV2, PH_QAG_FIRST, PH_QAG_BISECT, PH_DONE };
+
+// Wave-uniform state of one coefficient.  It is only touched between batches of
+// gamma-integrals, so it is parked in LDS while a batch runs: the vector
+// registers stay free for the integrand.
+struct TaskState {
+    double ans;                                   // compute(): running sum
+    double ni_ans, contrib, delta_n, incr, n_start;   // n_integration locals
+    double dr_h, dr_r0, dr_err;                   // deriv_central locals
+    double qa, qb;                                // chunk limits
+    long long disc_next;                          // next discrete harmonic to post
+    int chunks, lobe, phase, ni_failed, status;
+    QagState oq;                                  // outer QAG over n
+};
+
+__device__ inline SymOrder uniform_order(SymOrder so)
+{
+    so.n = uni(so.n);
+    so.small = uni(so.small);
+    so.np1_small = uni(so.np1_small);
+    so.dj_nan = uni(so.dj_nan);
+    LeungOrder *os[2] = { &so.o0, &so.o1 };
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        LeungOrder &o = *os[k];
+        o.n = uni(o.n); o.thr_lo = uni(o.thr_lo); o.thr_hi = uni(o.thr_hi); o.thr_plus_lo = uni(o.thr_plus_lo);
+        o.ninv = uni(o.ninv); o.np1 = uni(o.np1); o.vsum2 = uni(o.vsum2); o.lgam = uni(o.lgam);
+        o.small_eps_const = uni(o.small_eps_const); o.big_n = uni(o.big_n);
+    }
+    return so;
+}
+
+template <int KIND>
+__device__ inline double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
+                                              const IStore &inner, const IStore &outer, TaskState *park,
+                                              QagPark *qpark, int &status_out)
+{
+    const double N_MAX = 30.;
+    const int lane = g.lane;
+    const bool is_v = pt.stokes == STOKES_V;
+
+    const double n_minus = pt.s * rim_fabs(pt.sin_th);
+    const long long n_lo = sat_i64(n_minus + 1.);
+    const long long n_hi = sat_i64(n_minus + 1. + N_MAX);
+
+    TaskState T;
+    T.ans = 0.;
+    T.status = ST_OK;
+    T.phase = PH_DISCRETE;
+    T.disc_next = n_lo;
+    T.lobe = 0;
+    T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.n_start = 0.;
+    T.chunks = 0;
+    T.ni_failed = 0;
+    T.dr_h = 0.; T.dr_r0 = 0.; T.dr_err = 0.;
+    T.qa = 0.; T.qb = 0.;
+    qag_begin(T.oq, 0., 1e-3, 1000);
+
+    // n_integration prologue (symphony.rs:197-215)
+    auto start_lobe = [&](int which) {
+        T.lobe = which;
+        T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.chunks = 0;
+        T.ni_failed = 0;
+        T.n_start = rim_floor(n_minus + 1. + N_MAX);
+        if (pt.s < 10.) { T.delta_n = 1.; T.incr = 2.; }
+    };
+
+    // What follows once the current lobe's n_integration has ended (symphony.rs:127-146).
+    auto end_of_lobe = [&]() -> int {
+        const double c = T.ni_failed ? RIM_NAN : T.ni_ans;
+        T.ans += c;
+        if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; return PH_DONE; }
+        if (is_v && T.lobe == 0) {
+            start_lobe(1);
+            return PH_DERIV1;   // the caller re-checks the while condition for the new lobe
+        }
+        return PH_DONE;
+    };
+
+    // while-condition of n_integration (symphony.rs:225) + chunk cap
+    auto chunk_loop_head = [&]() -> int {
+        for (;;) {
+            if (!(rim_fabs(T.contrib) >= rim_fabs(T.ni_ans / 1e5))) {
+                if (end_of_lobe() == PH_DONE) return PH_DONE;
+                continue;
+            }
+            if (++T.chunks > RIM_MAX_CHUNKS) {
+                T.status |= ST_CHUNK_CAP;
+                T.ni_failed = 1;
+                if (end_of_lobe() == PH_DONE) return PH_DONE;
+                continue;
+            }
+            T.dr_h = 1e-10 * T.n_start;
+            return PH_DERIV1;
+        }
+    };
+
+    if (n_hi <= n_lo) {
+        // no discrete harmonics (only for absurd n_minus): straight to the tail
+        start_lobe(0);
+        T.phase = chunk_loop_head();
+    }
+
+    while (T.phase != PH_DONE) {
+        // ---- 1. post a batch of (n, lobe) requests, one per lane ----------------
+        double req_n = 0.;
+        int req_lobe = 0;
+        bool req_active = false;
+        int n_req = 0;
+        const int phase = T.phase;
+
+        if (phase == PH_DISCRETE) {
+            // up to 31 harmonics per batch; for V the two lobes of a harmonic sit on adjacent lanes
+            const int per = is_v ? 2 : 1;
+            const long long remaining = n_hi - T.disc_next;
+            const int cnt = remaining > 31 ? 31 : (int) remaining;
+            n_req = cnt * per;
+            if (lane < n_req) {
+                req_n = (double) (T.disc_next + lane / per);
+                req_lobe = is_v ? (lane & 1) : 0;
+                req_active = true;
+            }
+        } else if (phase == PH_DERIV1 || phase == PH_DERIV2) {
+            // central_deriv: f(x-h), f(x+h), f(x-h/2), f(x+h/2)  (deriv.c order)
+            n_req = 4;
+            if (lane < 4) {
+                const double h = T.dr_h;
+                req_n = (lane == 0) ? T.n_start - h : (lane == 1) ? T.n_start + h
+                      : (lane == 2) ? T.n_start - h / 2 : T.n_start + h / 2;
+                req_lobe = T.lobe;
+                req_active = true;
+            }
+        } else if (phase == PH_QAG_FIRST) {
+            const double center = 0.5 * (T.qa + T.qb);
+            const double hl = 0.5 * (T.qb - T.qa);
+            req_n = center + hl * g.t;
+            req_lobe = T.lobe;
+            req_active = g.node && g.half == 0;
+        } else {   // PH_QAG_BISECT
+            qag_pick(T.oq, outer, lane);
+            const double la = g.half ? T.oq.a2 : T.oq.a1;
+            const double lb = g.half ? T.oq.b2 : T.oq.b1;
+            const double center = 0.5 * (la + lb);
+            const double hl = 0.5 * (lb - la);
+            req_n = center + hl * g.t;
+            req_lobe = T.lobe;
+            req_active = g.node;
+        }
+
+        // park the uniform state in LDS while the batch runs
+        if (lane == 0) *park = T;
+        int batch_status = 0;
+
+        // ---- 2. evaluate the requests: the only copy of the inner QAG ------------
+        double gval = 0.;
+        {
+            unsigned long long mask = __ballot(req_active);
+            while (mask) {
+                const int k = __ffsll((long long) mask) - 1;
+                mask &= mask - 1;
+                const double n = readlane_d(req_n, k);
+                const int lb = __builtin_amdgcn_readlane(req_lobe, k);
+                const SymOrder so = uniform_order(sym_order(n));
+                GammaLimits L = gamma_limits(pt, n, lb);
+                L.g0 = uni(L.g0);
+                L.g1 = uni(L.g1);
+                auto f = [&](double x, bool active) -> double {
+                    return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
+                };
+                QagState iq;
+                wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, iq, qpark);
+                if (lane == 0) qpark->ctr.inner_qags += 1;
+                double val = iq.result;
+                if (iq.status != QAG_SUCCESS) {
+                    val = RIM_NAN;
+                    batch_status |= ST_INNER_FAIL;
+                    if (iq.status == QAG_ESTORE) batch_status |= ST_STORE_FULL;
+                }
+                if (lane == k) gval = val;
+            }
+        }
+
+        __syncthreads();
+        T = *park;
+        T.status |= batch_status;
+
+        // ---- 3. continuation of the posting phase --------------------------------
+        if (phase == PH_DISCRETE) {
+            for (int k = 0; k < n_req; k++) T.ans += readlane_d(gval, k);
+            const int per = is_v ? 2 : 1;
+            T.disc_next += n_req / per;
+            if (T.disc_next < n_hi) continue;
+            if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; break; }
+            start_lobe(0);
+            T.phase = chunk_loop_head();
+            continue;
+        }
+
+        if (phase == PH_DERIV1 || phase == PH_DERIV2) {
+            const double fm1 = readlane_d(gval, 0), fp1 = readlane_d(gval, 1);
+            const double fmh = readlane_d(gval, 2), fph = readlane_d(gval, 3);
+            const double h = T.dr_h;
+            const double x = T.n_start;
+            const double r3 = 0.5 * (fp1 - fm1);
+            const double r5 = (4.0 / 3.0) * (fph - fmh) - (1.0 / 3.0) * r3;
+            const double e3 = (rim_fabs(fp1) + rim_fabs(fm1)) * RIM_DBL_EPSILON;
+            const double e5 = 2.0 * (rim_fabs(fph) + rim_fabs(fmh)) * RIM_DBL_EPSILON + e3;
+            const double dy = rim_max(rim_fabs(r3 / h), rim_fabs(r5 / h)) * (rim_fabs(x) / h) * RIM_DBL_EPSILON;
+            const double res = r5 / h;
+            const double trunc = rim_fabs((r5 - r3) / h);
+            const double round = rim_fabs(e5 / h) + dy;
+
+            if (phase == PH_DERIV1) {
+                T.dr_r0 = res;
+                T.dr_err = round + trunc;
+                if (round < trunc && (round > 0 && trunc > 0)) {
+                    T.dr_h = (1e-10 * T.n_start) * rim_pow(round / (2.0 * trunc), 1.0 / 3.0);
+                    T.phase = PH_DERIV2;
+                    continue;
+                }
+            } else {
+                const double error_opt = round + trunc;
+                if (error_opt < T.dr_err && rim_fabs(res - T.dr_r0) < 4.0 * T.dr_err) {
+                    T.dr_r0 = res;
+                    T.dr_err = error_opt;
+                }
+            }
+            const double deriv = T.dr_r0;
+
+            if (deriv == 0. || (T.contrib != 0. && rim_fabs(deriv / T.contrib) < 1e-5)) T.delta_n *= T.incr;
+            if (T.delta_n < T.n_start / T.incr) T.delta_n *= T.incr;
+
+            T.qa = T.n_start;
+            T.qb = T.n_start + T.delta_n;
+            qag_begin(T.oq, 0., 1e-3, 1000);
+            T.phase = PH_QAG_FIRST;
+            continue;
+        }
+
+        // outer GK31 over the values now sitting in the lanes
+        bool chunk_done;
+        if (phase == PH_QAG_FIRST) {
+            const double hl = 0.5 * (T.qb - T.qa);
+            const GKRes r = wave_gk31(gval, hl, g);
+            chunk_done = qag_after_first(T.oq, outer, lane, T.qa, T.qb, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
+                                         readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
+        } else {
+            const double la = g.half ? T.oq.a2 : T.oq.a1;
+            const double lb = g.half ? T.oq.b2 : T.oq.b1;
+            const double hl = 0.5 * (lb - la);
+            const GKRes r = wave_gk31(gval, hl, g);
+            chunk_done = qag_after_bisect(T.oq, outer, lane,
+                                          readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
+                                          readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+        }
+        if (!chunk_done) { T.phase = PH_QAG_BISECT; continue; }
+
+        if (T.oq.status != QAG_SUCCESS) {
+            // `?` in n_integration (symphony.rs:269): the whole n integration is an Err
+            T.status |= ST_OUTER_FAIL;
+            if (T.oq.status == QAG_ESTORE) T.status |= ST_STORE_FULL;
+            T.ni_failed = 1;
+            T.phase = end_of_lobe();
+            if (T.phase != PH_DONE) T.phase = chunk_loop_head();
+            continue;
+        }
+        T.contrib = T.oq.result;
+        T.ni_ans += T.contrib;
+        T.n_start += T.delta_n;
+        if (T.n_start > 1e13) T.incr = 1.;
+        T.phase = chunk_loop_head();
+    }
+
+    status_out = T.status;
+    double ans = T.ans;
+    if (!rim_isfinite(ans)) {
+        status_out |= ST_NONFINITE;
+        return RIM_NAN;
+    }
+
+    const double tpe = RIM_TWO_PI * RIM_ELECTRON_CHARGE;
+    const double acos_th = rim_fabs(pt.cos_th);
+    if (pt.coeff == COEFF_EMISSION)
+        ans = ans * ((tpe * tpe) / (RIM_SPEED_LIGHT * acos_th));
+    else
+        ans = ans * (-1. * (tpe * tpe) / (2. * RIM_MASS_ELECTRON * RIM_SPEED_LIGHT * acos_th));
+    return ans;
+}
+
+}  // namespace rim
+#endif

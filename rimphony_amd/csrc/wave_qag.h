@@ -1,0 +1,395 @@
+// wave_qag.h -- wavefront-cooperative Gauss-Kronrod 31 and adaptive QAG for gfx950.
+//
+// Replaces gsl_integration_qag(key = GK31) as the reference drives it through
+// src/gsl.rs:156-207 (QUADPACK dqage/dqk31; algorithm restated in
+// oracle/rimo_quad.c).  Design:
+//
+//   * One 64-lane wavefront owns one integral.  The 31 Kronrod nodes of an
+//     interval sit on lanes 0..30 of a 32-lane half-wave (lane 31 is padding
+//     with zero weight); each lane keeps its abscissa and its two weights in
+//     registers (loaded once from the LDS copy of the table).
+//   * A bisection evaluates BOTH children in one pass: left child on lanes
+//     0..31, right child on lanes 32..63 (62 of 64 lanes busy).
+//   * The four rule sums (Kronrod, Gauss, |f|, |f - mean|) are 5-step xor
+//     butterflies inside each half-wave.  Floating-point addition commutes, so
+//     every lane of a half ends with the same bits: the value of a fixed
+//     balanced binary tree over the 32 lanes.  The CPU oracle sums in the same
+//     tree order, which is what makes results comparable bit for bit.
+//   * The subinterval list (alist/blist/rlist/elist of the GSL workspace) lives
+//     in LDS, wave-private.  GSL's sorted `order` list is replaced by a
+//     wave-wide argmax over (error, insertion stamp): GSL inserts a new entry
+//     in front of entries of equal error, so "largest error, latest insertion
+//     wins ties" selects the same interval (exact while the list is shorter
+//     than limit/2 + 2, beyond which GSL stops keeping it fully sorted; the LDS
+//     capacity is far below that).  After the first bisection GSL always takes
+//     slot 0 (qpsrt's `last < 2` shortcut); so do we.
+//
+// All bookkeeping values are wave-uniform; they are computed redundantly by
+// every lane (there is no scalar fp64 unit) so no broadcast is needed.
+#ifndef RIM_WAVE_QAG_H
+#define RIM_WAVE_QAG_H
+
+#include <hip/hip_runtime.h>
+#include "detmath.h"
+#include "gk31_table.h"
+
+namespace rim {
+
+enum {
+    QAG_SUCCESS = 0, QAG_EFAILED = 5, QAG_EMAXITER = 11, QAG_EBADTOL = 13, QAG_EROUND = 18, QAG_ESING = 21,
+    QAG_ESTORE = 1001   // LDS subinterval store exhausted (not a GSL code)
+};
+
+__constant__ double c_gk_x[32] = RIM_GK31_X;
+__constant__ double c_gk_wk[32] = RIM_GK31_WK;
+__constant__ double c_gk_wg[32] = RIM_GK31_WG;
+
+struct GKLane {
+    double t, wk, wg;   // abscissa in [-1, 1], Kronrod weight, Gauss weight of this lane's node
+    int lane, half, j;
+    bool node;          // j < 31
+};
+
+// LDS image of the rule + per-lane registers.  tab must hold 96 doubles.
+__device__ inline GKLane gk_lane_init(double *tab)
+{
+    GKLane g;
+    g.lane = threadIdx.x & 63;
+    g.half = g.lane >> 5;
+    g.j = g.lane & 31;
+    g.node = g.j < 31;
+    if (g.lane < 32) {
+        tab[g.lane] = c_gk_x[g.lane];
+        tab[32 + g.lane] = c_gk_wk[g.lane];
+        tab[64 + g.lane] = c_gk_wg[g.lane];
+    }
+    __syncthreads();
+    g.t = tab[g.j];
+    g.wk = tab[32 + g.j];
+    g.wg = tab[64 + g.j];
+    return g;
+}
+
+__device__ inline double readlane_d(double v, int srclane)
+{
+    const unsigned long long u = (unsigned long long) __double_as_longlong(v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, srclane);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), srclane);
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+
+// Mark a wave-uniform value as such: the result lives in SGPRs, which keeps the
+// long-lived per-point / per-order constants out of the vector register file.
+__device__ inline double uni(double v)
+{
+    const unsigned long long u = (unsigned long long) __double_as_longlong(v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) u);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (u >> 32));
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int) v) != 0; }
+
+// Sum over the 32 lanes of each half-wave; all lanes of a half receive the sum.
+__device__ inline double half_sum(double v)
+{
+    v = v + __shfl_xor(v, 1);
+    v = v + __shfl_xor(v, 2);
+    v = v + __shfl_xor(v, 4);
+    v = v + __shfl_xor(v, 8);
+    v = v + __shfl_xor(v, 16);
+    return v;
+}
+
+struct GKRes { double result, abserr, resabs, resasc; };
+
+// qk.c: rescale_error
+__device__ inline double rescale_error(double err, double result_abs, double result_asc)
+{
+    err = rim_fabs(err);
+    if (result_asc != 0 && err != 0) {
+        const double scale = rim_pow((200 * err / result_asc), 1.5);
+        if (scale < 1) err = result_asc * scale;
+        else err = result_asc;
+    }
+    if (result_abs > RIM_DBL_MIN / (50 * RIM_DBL_EPSILON)) {
+        const double min_err = 50 * RIM_DBL_EPSILON * result_abs;
+        if (min_err > err) err = min_err;
+    }
+    return err;
+}
+
+// Apply the rule to the samples fv (one per lane; 0 on padding/inactive lanes).
+// half_length is the lane's interval half-length (uniform within a half-wave).
+__device__ inline GKRes wave_gk31(double fv, double half_length, const GKLane &g)
+{
+    double rk = half_sum(g.wk * fv);
+    const double rg = half_sum(g.wg * fv);
+    double ra = half_sum(g.wk * rim_fabs(fv));
+    const double mean = rk * 0.5;
+    double rasc = half_sum(g.wk * rim_fabs(fv - mean));
+    const double ahl = rim_fabs(half_length);
+    const double err = (rk - rg) * half_length;
+    rk *= half_length;
+    ra *= ahl;
+    rasc *= ahl;
+    GKRes r;
+    r.result = rk;
+    r.resabs = ra;
+    r.resasc = rasc;
+    r.abserr = rescale_error(err, ra, rasc);
+    return r;
+}
+
+// ---- subinterval store ------------------------------------------------------
+
+struct IStore {
+    double *a, *b, *r, *e;   // LDS, [cap]
+    int *stamp;
+    int cap;
+};
+
+__device__ inline IStore istore_carve(double *base, int cap)
+{
+    IStore s;
+    s.a = base;
+    s.b = base + cap;
+    s.r = base + 2 * cap;
+    s.e = base + 3 * cap;
+    s.stamp = (int *) (base + 4 * cap);
+    s.cap = cap;
+    return s;
+}
+// doubles needed per store
+#define RIM_ISTORE_DOUBLES(cap) (4 * (cap) + ((cap) + 1) / 2)
+
+// ---- QAG bookkeeping (qag.c), shared by the inner and the outer integrals ----
+
+struct QagState {
+    double epsabs, epsrel;
+    int limit;
+    double area, errsum, tolerance;
+    int iteration, rt1, rt2, error_type, size, imax;
+    double a1, b1, a2, b2, r_i, e_i;   // children of the interval being bisected
+    int status;
+    double result, abserr;
+};
+
+__device__ inline void qag_begin(QagState &q, double epsabs, double epsrel, int limit)
+{
+    q.epsabs = epsabs;
+    q.epsrel = epsrel;
+    q.limit = limit;
+    q.iteration = 0;
+    q.rt1 = q.rt2 = q.error_type = 0;
+    q.size = 0;
+    q.imax = 0;
+    q.status = QAG_SUCCESS;
+    q.result = 0.;
+    q.abserr = 0.;
+    q.area = q.errsum = q.tolerance = 0.;
+}
+
+// After the first rule application on [a, b].  Returns true when finished.
+__device__ inline bool qag_after_first(QagState &q, const IStore &st, int lane, double a, double b,
+                                       double result0, double abserr0, double resabs0, double resasc0)
+{
+    if (q.epsabs <= 0 && (q.epsrel < 50 * RIM_DBL_EPSILON || q.epsrel < 0.5e-28)) {
+        q.status = QAG_EBADTOL;
+        q.result = 0.;
+        return true;
+    }
+    if (lane == 0) {
+        st.a[0] = a; st.b[0] = b; st.r[0] = result0; st.e[0] = abserr0; st.stamp[0] = 0;
+    }
+    q.size = 1;
+    q.tolerance = rim_max(q.epsabs, q.epsrel * rim_fabs(result0));
+    const double round_off = 50 * RIM_DBL_EPSILON * resabs0;
+    q.result = result0;
+    q.abserr = abserr0;
+    if (abserr0 <= round_off && abserr0 > q.tolerance) { q.status = QAG_EROUND; return true; }
+    if ((abserr0 <= q.tolerance && abserr0 != resasc0) || abserr0 == 0.0) { q.status = QAG_SUCCESS; return true; }
+    if (q.limit == 1) { q.status = QAG_EMAXITER; return true; }
+    q.area = result0;
+    q.errsum = abserr0;
+    q.iteration = 1;
+    q.imax = 0;
+    return false;
+}
+
+// Choose the interval to bisect and set up its two children.
+__device__ inline void qag_pick(QagState &q, const IStore &st, int lane)
+{
+    __syncthreads();   // make lane 0's store writes visible to the whole wave
+    int imax = 0;
+    if (q.size > 2) {
+        // wave-wide argmax over (error, stamp)
+        double be = -1.0;
+        int bs = -1, bi = 0;
+        for (int i = lane; i < q.size; i += 64) {
+            const double e = st.e[i];
+            const int s = st.stamp[i];
+            if (e > be || (e == be && s > bs)) { be = e; bs = s; bi = i; }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const double oe = __shfl_xor(be, m);
+            const int os = __shfl_xor(bs, m);
+            const int oi = __shfl_xor(bi, m);
+            if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+        }
+        imax = __builtin_amdgcn_readfirstlane(bi);
+    }
+    q.imax = imax;
+    const double a_i = st.a[imax], b_i = st.b[imax];
+    q.r_i = st.r[imax];
+    q.e_i = st.e[imax];
+    q.a1 = a_i;
+    q.b1 = 0.5 * (a_i + b_i);
+    q.a2 = q.b1;
+    q.b2 = b_i;
+}
+
+__device__ inline bool subinterval_too_small(double a1, double a2, double b2)
+{
+    const double tmp = (1 + 100 * RIM_DBL_EPSILON) * (rim_fabs(a2) + 1000 * RIM_DBL_MIN);
+    return rim_fabs(a1) <= tmp && rim_fabs(b2) <= tmp;
+}
+
+// After both children have been evaluated.  Returns true when the QAG is finished
+// (q.status / q.result set).
+__device__ inline bool qag_after_bisect(QagState &q, const IStore &st, int lane,
+                                        double area1, double error1, double resasc1,
+                                        double area2, double error2, double resasc2)
+{
+    const double area12 = area1 + area2;
+    const double error12 = error1 + error2;
+
+    q.errsum += (error12 - q.e_i);
+    q.area += area12 - q.r_i;
+
+    if (resasc1 != error1 && resasc2 != error2) {
+        const double delta = q.r_i - area12;
+        if (rim_fabs(delta) <= 1.0e-5 * rim_fabs(area12) && error12 >= 0.99 * q.e_i) q.rt1++;
+        if (q.iteration >= 10 && error12 > q.e_i) q.rt2++;
+    }
+
+    q.tolerance = rim_max(q.epsabs, q.epsrel * rim_fabs(q.area));
+
+    if (q.errsum > q.tolerance) {
+        if (q.rt1 >= 6 || q.rt2 >= 20) q.error_type = 2;
+        if (subinterval_too_small(q.a1, q.a2, q.b2)) q.error_type = 3;
+    }
+
+    // update(): the child with the larger error keeps the parent's slot
+    bool overflow = false;
+    if (q.size >= st.cap) {
+        overflow = true;
+    } else {
+        __syncthreads();   // all lanes have finished reading the parent's slot
+        if (lane == 0) {
+            const int inew = q.size;
+            const int im = q.imax;
+            if (error2 > error1) {
+                st.a[im] = q.a2; st.r[im] = area2; st.e[im] = error2;
+                st.a[inew] = q.a1; st.b[inew] = q.b1; st.r[inew] = area1; st.e[inew] = error1;
+            } else {
+                st.b[im] = q.b1; st.r[im] = area1; st.e[im] = error1;
+                st.a[inew] = q.a2; st.b[inew] = q.b2; st.r[inew] = area2; st.e[inew] = error2;
+            }
+            st.stamp[im] = 2 * q.iteration;
+            st.stamp[inew] = 2 * q.iteration + 1;
+        }
+        q.size++;
+    }
+    q.iteration++;
+
+    if (!overflow && q.iteration < q.limit && !q.error_type && q.errsum > q.tolerance)
+        return false;   // keep bisecting
+
+    __syncthreads();
+    double sum = 0;
+    for (int k = 0; k < q.size; k++) sum += st.r[k];
+    q.result = sum;
+    q.abserr = q.errsum;
+
+    if (q.errsum <= q.tolerance) q.status = QAG_SUCCESS;
+    else if (overflow) q.status = QAG_ESTORE;
+    else if (q.error_type == 2) q.status = QAG_EROUND;
+    else if (q.error_type == 3) q.status = QAG_ESING;
+    else if (q.iteration == q.limit) q.status = QAG_EMAXITER;
+    else q.status = QAG_EFAILED;
+    return true;
+}
+
+// Work counters, wave-private in LDS (lane 0 updates them).
+struct WaveCounters {
+    unsigned long long samples;   // integrand samples (active lanes)
+    unsigned long long steps;     // wave-wide integrand passes (each costs one full-wave evaluation)
+    unsigned long long inner_qags;
+};
+
+// LDS scratch of one wave's QAG: the bookkeeping state is parked here while the
+// integrand runs, so that the integrand has the vector register file to itself.
+struct QagPark {
+    QagState q;
+    WaveCounters ctr;
+};
+
+// Adaptive QAG of a per-lane integrand f(x): one wave, one integral.
+// f is called once per pass with the lane's abscissa and an `active` flag and
+// must return 0 for inactive lanes.
+template <class F>
+__device__ inline void wave_qag(F &f, const GKLane &g, const IStore &st, double a, double b,
+                                double epsabs, double epsrel, int limit, QagState &q, QagPark *park)
+{
+    qag_begin(q, epsabs, epsrel, limit);
+    bool first = true;
+    for (;;) {
+        double la, lb;
+        bool active;
+        if (first) {
+            la = a; lb = b;
+            active = g.node && g.half == 0;
+        } else {
+            qag_pick(q, st, g.lane);
+            la = g.half ? q.a2 : q.a1;
+            lb = g.half ? q.b2 : q.b1;
+            active = g.node;
+        }
+        double fv;
+        {
+            const double center = 0.5 * (la + lb);
+            const double hl = 0.5 * (lb - la);
+            const double x = center + hl * g.t;
+            if (g.lane == 0) {
+                park->q = q;
+                park->ctr.samples += first ? 31 : 62;
+                park->ctr.steps += 1;
+            }
+            fv = f(x, active);
+            __syncthreads();
+            q = park->q;
+        }
+        if (first) {
+            const double hl = 0.5 * (b - a);
+            const GKRes r = wave_gk31(fv, hl, g);
+            first = false;
+            if (qag_after_first(q, st, g.lane, a, b, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
+                                readlane_d(r.resabs, 0), readlane_d(r.resasc, 0)))
+                return;
+        } else {
+            const double la2 = g.half ? q.a2 : q.a1;
+            const double lb2 = g.half ? q.b2 : q.b1;
+            const double hl = 0.5 * (lb2 - la2);
+            const GKRes r = wave_gk31(fv, hl, g);
+            if (qag_after_bisect(q, st, g.lane,
+                                 readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
+                                 readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32)))
+                return;
+        }
+    }
+}
+
+}  // namespace rim
+#endif

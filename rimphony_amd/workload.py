@@ -1,0 +1,74 @@
+"""Synthetic parameter batches for the BASELINE.json configurations.
+
+Counter-based so that every consumer (numpy here, any C/HIP driver later) draws
+identical bits:  u(i, j) = (splitmix64(seed ^ (16 i + j)) >> 11) * 2^-53  for
+point i, parameter j.  Sampling laws follow the reference's Sampler
+(test-support/src/lib.rs:31-64: uniform, or log-uniform via exp(U[ln lo, ln hi]))
+over the span of its own drivers and golden file.
+"""
+import numpy as np
+
+SEED_BASE = 20250614
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, idx, j):
+    with np.errstate(over="ignore"):
+        key = np.uint64(seed) ^ (idx.astype(np.uint64) * np.uint64(16) + np.uint64(j))
+        r = splitmix64(key)
+    return (r >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _lin(u, lo, hi):
+    return lo + u * (hi - lo)
+
+
+def _log(u, lo, hi):
+    return np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo)))
+
+
+# kind ids match include/rimphony_hip.h
+POWER_LAW, THERMAL_JUETTNER, PITCHY_PL, PITCHY_KAPPA = 0, 1, 2, 3
+
+CONFIGS = {
+    # name: (kind, seed offset, coefficient mask)
+    "cfg2_powerlaw_jI_aI": (POWER_LAW, 0, 0x03),
+    "cfg2_powerlaw_8": (POWER_LAW, 0, 0xFF),
+    "cfg3_thermal_8": (THERMAL_JUETTNER, 1, 0xFF),
+    "cfg4_pitchypl_8": (PITCHY_PL, 2, 0xFF),
+    "cfg5_pitchykappa_8": (PITCHY_KAPPA, 3, 0xFF),
+}
+
+
+def make_batch(config, n, start=0):
+    """Return (kind, mask, s, theta, [params...]) for points start .. start+n-1 of a config."""
+    kind, off, mask = CONFIGS[config]
+    seed = SEED_BASE + off
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    s = _log(uniform01(seed, idx, 0), 0.1, 1e4)
+    theta = _lin(uniform01(seed, idx, 1), 0.05, 1.52)
+    ones = np.ones(n)
+    if kind == POWER_LAW:
+        p = _lin(uniform01(seed, idx, 2), 1.5, 4.0)
+        gmin = _log(uniform01(seed, idx, 3), 1.0, 30.0)
+        params = [p, gmin, 1e12 * ones, 1e10 * ones]
+    elif kind == THERMAL_JUETTNER:
+        params = [_log(uniform01(seed, idx, 2), 0.1, 100.0)]
+    elif kind == PITCHY_PL:
+        p = _lin(uniform01(seed, idx, 2), 1.5, 4.0)
+        k = _lin(uniform01(seed, idx, 3), 0.0, 3.0)
+        params = [p, k, ones.copy(), 1e12 * ones, 1e10 * ones]
+    else:
+        kappa = _lin(uniform01(seed, idx, 2), 1.5, 4.5)
+        width = _log(uniform01(seed, idx, 3), np.e, np.e ** 3)
+        k = _lin(uniform01(seed, idx, 4), 0.0, 3.0)
+        params = [kappa, width, k, 1e10 * ones]
+    return kind, mask, s, theta, params
