@@ -30,6 +30,7 @@ namespace rim {
 #define RIM_SPEED_LIGHT 2.99792458e10
 #define RIM_ELECTRON_CHARGE 4.80320680e-10
 #define RIM_MAX_CHUNKS 4096
+#define RIM_MAX_BATCHES (1 << 22)   // backstop: no coefficient needs anywhere near this many batches
 
 // status bits reported per coefficient
 enum {
@@ -43,7 +44,7 @@ enum {
 };
 
 // Rust `x as i64`: truncate toward zero, saturating, NaN -> 0
-__device__ inline long long sat_i64(double x)
+__device__ __forceinline__ long long sat_i64(double x)
 {
     if (!(x == x)) return 0;
     if (x >= 9223372036854775807.0) return 9223372036854775807LL;
@@ -54,7 +55,7 @@ __device__ inline long long sat_i64(double x)
 // gamma_integral (symphony.rs:312-389): limits for order n and lobe.
 struct GammaLimits { double g0, g1; };
 
-__device__ inline GammaLimits gamma_limits(const SymPoint &pt, double n, int negative_lobe)
+__device__ __forceinline__ GammaLimits gamma_limits(const SymPoint &pt, double n, int negative_lobe)
 {
     const double s = pt.s;
     const double acos_th = rim_fabs(pt.cos_th);
@@ -89,11 +90,11 @@ struct TaskState {
     double dr_h, dr_r0, dr_err;                   // deriv_central locals
     double qa, qb;                                // chunk limits
     long long disc_next;                          // next discrete harmonic to post
-    int chunks, lobe, phase, ni_failed, status;
+    int chunks, lobe, phase, ni_failed, status, batches;
     QagState oq;                                  // outer QAG over n
 };
 
-__device__ inline SymOrder uniform_order(SymOrder so)
+__device__ __forceinline__ SymOrder uniform_order(SymOrder so)
 {
     so.n = uni(so.n);
     so.small = uni(so.small);
@@ -111,7 +112,7 @@ __device__ inline SymOrder uniform_order(SymOrder so)
 }
 
 template <int KIND>
-__device__ inline double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
+__device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
                                               const IStore &inner, const IStore &outer, TaskState *park,
                                               QagPark *qpark, int &status_out)
 {
@@ -131,6 +132,7 @@ __device__ inline double symphony_coefficient(const SymPoint &pt, const DistPara
     T.lobe = 0;
     T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.n_start = 0.;
     T.chunks = 0;
+    T.batches = 0;
     T.ni_failed = 0;
     T.dr_h = 0.; T.dr_r0 = 0.; T.dr_err = 0.;
     T.qa = 0.; T.qb = 0.;
@@ -182,6 +184,11 @@ __device__ inline double symphony_coefficient(const SymPoint &pt, const DistPara
     }
 
     while (T.phase != PH_DONE) {
+        if (++T.batches > RIM_MAX_BATCHES) {
+            T.status |= ST_CHUNK_CAP;
+            T.ans = RIM_NAN;
+            break;
+        }
         // ---- 1. post a batch of (n, lobe) requests, one per lane ----------------
         double req_n = 0.;
         int req_lobe = 0;
@@ -234,12 +241,12 @@ __device__ inline double symphony_coefficient(const SymPoint &pt, const DistPara
         // ---- 2. evaluate the requests: the only copy of the inner QAG ------------
         double gval = 0.;
         {
-            unsigned long long mask = __ballot(req_active);
+            unsigned long long mask = wv_ballot(req_active);
             while (mask) {
-                const int k = __ffsll((long long) mask) - 1;
+                const int k = __builtin_ffsll((long long) mask) - 1;
                 mask &= mask - 1;
                 const double n = readlane_d(req_n, k);
-                const int lb = __builtin_amdgcn_readlane(req_lobe, k);
+                const int lb = wv_readlane(req_lobe, k);
                 const SymOrder so = uniform_order(sym_order(n));
                 GammaLimits L = gamma_limits(pt, n, lb);
                 L.g0 = uni(L.g0);
@@ -260,7 +267,7 @@ __device__ inline double symphony_coefficient(const SymPoint &pt, const DistPara
             }
         }
 
-        __syncthreads();
+        wv_sync();
         T = *park;
         T.status |= batch_status;
 

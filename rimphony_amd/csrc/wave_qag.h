@@ -29,11 +29,26 @@
 #ifndef RIM_WAVE_QAG_H
 #define RIM_WAVE_QAG_H
 
+#if defined(RIM_WAVE_EMU)
+#include "wave_emu.h"      // tests/support: 64 host threads + barrier collectives (CPU debugging only)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include "detmath.h"
 #include "gk31_table.h"
 
 namespace rim {
+
+#if !defined(RIM_WAVE_EMU)
+// ---- wave primitives (gfx950) ---------------------------------------------------
+__device__ __forceinline__ int wv_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ void wv_sync() { __syncthreads(); }     // workgroup == one wave
+__device__ __forceinline__ int wv_readlane(int v, int srclane) { return __builtin_amdgcn_readlane(v, srclane); }
+__device__ __forceinline__ int wv_readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double wv_shfl_xor(double v, int m) { return __shfl_xor(v, m); }
+__device__ __forceinline__ int wv_shfl_xor(int v, int m) { return __shfl_xor(v, m); }
+__device__ __forceinline__ unsigned long long wv_ballot(bool p) { return __ballot(p); }
+#endif
 
 enum {
     QAG_SUCCESS = 0, QAG_EFAILED = 5, QAG_EMAXITER = 11, QAG_EBADTOL = 13, QAG_EROUND = 18, QAG_ESING = 21,
@@ -51,10 +66,10 @@ struct GKLane {
 };
 
 // LDS image of the rule + per-lane registers.  tab must hold 96 doubles.
-__device__ inline GKLane gk_lane_init(double *tab)
+__device__ __forceinline__ GKLane gk_lane_init(double *tab)
 {
     GKLane g;
-    g.lane = threadIdx.x & 63;
+    g.lane = wv_lane();
     g.half = g.lane >> 5;
     g.j = g.lane & 31;
     g.node = g.j < 31;
@@ -63,48 +78,48 @@ __device__ inline GKLane gk_lane_init(double *tab)
         tab[32 + g.lane] = c_gk_wk[g.lane];
         tab[64 + g.lane] = c_gk_wg[g.lane];
     }
-    __syncthreads();
+    wv_sync();
     g.t = tab[g.j];
     g.wk = tab[32 + g.j];
     g.wg = tab[64 + g.j];
     return g;
 }
 
-__device__ inline double readlane_d(double v, int srclane)
+__device__ __forceinline__ double readlane_d(double v, int srclane)
 {
-    const unsigned long long u = (unsigned long long) __double_as_longlong(v);
-    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, srclane);
-    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), srclane);
-    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+    const unsigned long long u = rim_bits(v);
+    const unsigned lo = (unsigned) wv_readlane((int) (unsigned) u, srclane);
+    const unsigned hi = (unsigned) wv_readlane((int) (unsigned) (u >> 32), srclane);
+    return rim_frombits(((unsigned long long) hi << 32) | lo);
 }
 
 // Mark a wave-uniform value as such: the result lives in SGPRs, which keeps the
 // long-lived per-point / per-order constants out of the vector register file.
-__device__ inline double uni(double v)
+__device__ __forceinline__ double uni(double v)
 {
-    const unsigned long long u = (unsigned long long) __double_as_longlong(v);
-    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) u);
-    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (u >> 32));
-    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+    const unsigned long long u = rim_bits(v);
+    const unsigned lo = (unsigned) wv_readfirstlane((int) (unsigned) u);
+    const unsigned hi = (unsigned) wv_readfirstlane((int) (unsigned) (u >> 32));
+    return rim_frombits(((unsigned long long) hi << 32) | lo);
 }
-__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int) v) != 0; }
+__device__ __forceinline__ int uni(int v) { return wv_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return wv_readfirstlane((int) v) != 0; }
 
 // Sum over the 32 lanes of each half-wave; all lanes of a half receive the sum.
-__device__ inline double half_sum(double v)
+__device__ __forceinline__ double half_sum(double v)
 {
-    v = v + __shfl_xor(v, 1);
-    v = v + __shfl_xor(v, 2);
-    v = v + __shfl_xor(v, 4);
-    v = v + __shfl_xor(v, 8);
-    v = v + __shfl_xor(v, 16);
+    v = v + wv_shfl_xor(v, 1);
+    v = v + wv_shfl_xor(v, 2);
+    v = v + wv_shfl_xor(v, 4);
+    v = v + wv_shfl_xor(v, 8);
+    v = v + wv_shfl_xor(v, 16);
     return v;
 }
 
 struct GKRes { double result, abserr, resabs, resasc; };
 
 // qk.c: rescale_error
-__device__ inline double rescale_error(double err, double result_abs, double result_asc)
+__device__ __forceinline__ double rescale_error(double err, double result_abs, double result_asc)
 {
     err = rim_fabs(err);
     if (result_asc != 0 && err != 0) {
@@ -121,7 +136,7 @@ __device__ inline double rescale_error(double err, double result_abs, double res
 
 // Apply the rule to the samples fv (one per lane; 0 on padding/inactive lanes).
 // half_length is the lane's interval half-length (uniform within a half-wave).
-__device__ inline GKRes wave_gk31(double fv, double half_length, const GKLane &g)
+__device__ __forceinline__ GKRes wave_gk31(double fv, double half_length, const GKLane &g)
 {
     double rk = half_sum(g.wk * fv);
     const double rg = half_sum(g.wg * fv);
@@ -149,7 +164,7 @@ struct IStore {
     int cap;
 };
 
-__device__ inline IStore istore_carve(double *base, int cap)
+__device__ __forceinline__ IStore istore_carve(double *base, int cap)
 {
     IStore s;
     s.a = base;
@@ -175,7 +190,7 @@ struct QagState {
     double result, abserr;
 };
 
-__device__ inline void qag_begin(QagState &q, double epsabs, double epsrel, int limit)
+__device__ __forceinline__ void qag_begin(QagState &q, double epsabs, double epsrel, int limit)
 {
     q.epsabs = epsabs;
     q.epsrel = epsrel;
@@ -191,7 +206,7 @@ __device__ inline void qag_begin(QagState &q, double epsabs, double epsrel, int 
 }
 
 // After the first rule application on [a, b].  Returns true when finished.
-__device__ inline bool qag_after_first(QagState &q, const IStore &st, int lane, double a, double b,
+__device__ __forceinline__ bool qag_after_first(QagState &q, const IStore &st, int lane, double a, double b,
                                        double result0, double abserr0, double resabs0, double resasc0)
 {
     if (q.epsabs <= 0 && (q.epsrel < 50 * RIM_DBL_EPSILON || q.epsrel < 0.5e-28)) {
@@ -218,9 +233,9 @@ __device__ inline bool qag_after_first(QagState &q, const IStore &st, int lane, 
 }
 
 // Choose the interval to bisect and set up its two children.
-__device__ inline void qag_pick(QagState &q, const IStore &st, int lane)
+__device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane)
 {
-    __syncthreads();   // make lane 0's store writes visible to the whole wave
+    wv_sync();   // make lane 0's store writes visible to the whole wave
     int imax = 0;
     if (q.size > 2) {
         // wave-wide argmax over (error, stamp)
@@ -233,12 +248,12 @@ __device__ inline void qag_pick(QagState &q, const IStore &st, int lane)
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
-            const double oe = __shfl_xor(be, m);
-            const int os = __shfl_xor(bs, m);
-            const int oi = __shfl_xor(bi, m);
+            const double oe = wv_shfl_xor(be, m);
+            const int os = wv_shfl_xor(bs, m);
+            const int oi = wv_shfl_xor(bi, m);
             if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
         }
-        imax = __builtin_amdgcn_readfirstlane(bi);
+        imax = wv_readfirstlane(bi);
     }
     q.imax = imax;
     const double a_i = st.a[imax], b_i = st.b[imax];
@@ -250,7 +265,7 @@ __device__ inline void qag_pick(QagState &q, const IStore &st, int lane)
     q.b2 = b_i;
 }
 
-__device__ inline bool subinterval_too_small(double a1, double a2, double b2)
+__device__ __forceinline__ bool subinterval_too_small(double a1, double a2, double b2)
 {
     const double tmp = (1 + 100 * RIM_DBL_EPSILON) * (rim_fabs(a2) + 1000 * RIM_DBL_MIN);
     return rim_fabs(a1) <= tmp && rim_fabs(b2) <= tmp;
@@ -258,7 +273,7 @@ __device__ inline bool subinterval_too_small(double a1, double a2, double b2)
 
 // After both children have been evaluated.  Returns true when the QAG is finished
 // (q.status / q.result set).
-__device__ inline bool qag_after_bisect(QagState &q, const IStore &st, int lane,
+__device__ __forceinline__ bool qag_after_bisect(QagState &q, const IStore &st, int lane,
                                         double area1, double error1, double resasc1,
                                         double area2, double error2, double resasc2)
 {
@@ -286,7 +301,7 @@ __device__ inline bool qag_after_bisect(QagState &q, const IStore &st, int lane,
     if (q.size >= st.cap) {
         overflow = true;
     } else {
-        __syncthreads();   // all lanes have finished reading the parent's slot
+        wv_sync();   // all lanes have finished reading the parent's slot
         if (lane == 0) {
             const int inew = q.size;
             const int im = q.imax;
@@ -307,7 +322,7 @@ __device__ inline bool qag_after_bisect(QagState &q, const IStore &st, int lane,
     if (!overflow && q.iteration < q.limit && !q.error_type && q.errsum > q.tolerance)
         return false;   // keep bisecting
 
-    __syncthreads();
+    wv_sync();
     double sum = 0;
     for (int k = 0; k < q.size; k++) sum += st.r[k];
     q.result = sum;
@@ -340,7 +355,7 @@ struct QagPark {
 // f is called once per pass with the lane's abscissa and an `active` flag and
 // must return 0 for inactive lanes.
 template <class F>
-__device__ inline void wave_qag(F &f, const GKLane &g, const IStore &st, double a, double b,
+__device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st, double a, double b,
                                 double epsabs, double epsrel, int limit, QagState &q, QagPark *park)
 {
     qag_begin(q, epsabs, epsrel, limit);
@@ -368,7 +383,7 @@ __device__ inline void wave_qag(F &f, const GKLane &g, const IStore &st, double 
                 park->ctr.steps += 1;
             }
             fv = f(x, active);
-            __syncthreads();
+            wv_sync();
             q = park->q;
         }
         if (first) {
