@@ -107,6 +107,16 @@ int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
  * the kernel to finish). */
 int rimphony_last_symphony_ms(rimphony_ctx *ctx, float *ms);
 
+/* Diagnostics: 16 heartbeat words in host-mapped memory, updated by the wave that
+ * works on task number `task` (= point * nslots + slot index) of subsequent
+ * batch calls while the kernel runs -- the counterpart of the reference drivers'
+ * "write the parameters before computing so a hang can be reconstructed"
+ * (examples/crank-out-pitchykappa.rs:193-200).  Words: [0] task+1, [1] batches,
+ * [2] phase, [3] integrand passes, [4] inner QAG iteration, [5] chunks,
+ * [6] n_start bits, [7] delta_n bits, [8] lane of the running gamma-integral,
+ * [9] its n (bits), [10] 1 when the task has finished. */
+int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_words);
+
 /* The batched compute(): N x (full_calculation + compute_all_dimensionless).
  *   d_s, d_theta   [n]                device
  *   d_params       host array of rimphony_dist_nparams(kind) DEVICE pointers, each [n]

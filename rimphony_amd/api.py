@@ -135,6 +135,13 @@ class Context:
         capi.check(self.lib.rimphony_last_symphony_ms(self.handle, ctypes.byref(ms)), "rimphony_last_symphony_ms")
         return float(ms.value)
 
+    def heartbeat(self, task=0):
+        """Diagnostics: returns a ctypes pointer to 16 host-mapped uint64 words (see rimphony_hip.h)."""
+        p = ctypes.POINTER(ctypes.c_uint64)()
+        capi.check(self.lib.rimphony_debug_heartbeat(self.handle, int(task), ctypes.byref(p)),
+                   "rimphony_debug_heartbeat")
+        return p
+
     def norm_batch(self, kind, params):
         dp = [self._as_dev(p) for p in params]
         n = dp[0].numel()

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double
     const GKLane g = gk_lane_init(s_tab);
     const IStore st = istore_carve(s_store, CAP_NORM);
     __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
     for (;;) {
         unsigned long long t = 0;
@@ -120,6 +120,8 @@ struct SymArgs {
     int nslots;
     int slot[8];
     unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
+    unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
+    unsigned long long hb_task;
 };
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
     const IStore inner = istore_carve(s_inner, CAP_INNER);
     const IStore outer = istore_carve(s_outer, CAP_OUTER);
     __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     for (;;) {
@@ -172,6 +174,12 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
         d.inv_kappa_width = uni(d.inv_kappa_width);
         d.neg_inverse_t = uni(d.neg_inverse_t);
 
+        if (g.lane == 0) {
+            s_qpark.hb = (a.heartbeat && t == a.hb_task) ? a.heartbeat : nullptr;
+            if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
+        }
+        __syncthreads();
+
         double val;
         int st = 0;
         if (!(norm == norm)) {
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
         if (g.lane == 0) {
             a.out[i * 8 + slot] = val;
             if (a.status) a.status[i * 8 + slot] = st;
+            if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
         }
     }
 
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const 
     const GKLane g = gk_lane_init(s_tab);
     const IStore inner = istore_carve(s_inner, CAP_INNER);
     __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
     SymPoint pt;
     pt.s = pa.s;
     rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(64) void qag_selftest_kernel(size_t count, const in
     const GKLane g = gk_lane_init(s_tab);
     const IStore st = istore_carve(s_store, CAP_NORM);
     __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
     for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
         const int fam = family[i];
         const double q0 = p0[i], q1 = p1[i];
@@ -308,6 +317,10 @@ struct rimphony_ctx {
     // HIP events bracketing the most recent symphony_kernel launch
     hipEvent_t ev_start, ev_stop;
     int ev_valid;
+    // diagnostics: heartbeat words in host-mapped memory
+    unsigned long long *hb_host;
+    unsigned long long *hb_dev;
+    unsigned long long hb_task;
 };
 
 #define HIP_TRY(expr)                                                            \
@@ -375,6 +388,7 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     if (c->d_in) (void) hipFree(c->d_in);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_status) (void) hipFree(c->d_status);
+    if (c->hb_host) (void) hipHostFree(c->hb_host);
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
     delete c;
@@ -487,6 +501,8 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     a.status = d_status;
     a.n = n;
     a.queue = c->d_queue;
+    a.heartbeat = c->hb_dev;
+    a.hb_task = c->hb_task;
     a.nslots = 0;
     uint32_t computed = 0;
     for (int k = 0; k < 6; k++)     // symphony slots: j/alpha x I,Q,V
@@ -509,6 +525,23 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         }
         if (rc) return rc;
     }
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_debug_heartbeat(rimphony_ctx *c, uint64_t task, uint64_t **host_words)
+{
+    if (!c || !host_words) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->hb_host) {
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, 16 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(h, 0, 16 * sizeof(unsigned long long));
+        HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+        c->hb_host = (unsigned long long *) h;
+        c->hb_dev = (unsigned long long *) d;
+    }
+    c->hb_task = task;
+    *host_words = (uint64_t *) c->hb_host;
     return RIMPHONY_OK;
 }
 

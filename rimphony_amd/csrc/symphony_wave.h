@@ -235,7 +235,16 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
         }
 
         // park the uniform state in LDS while the batch runs
-        if (lane == 0) *park = T;
+        if (lane == 0) {
+            *park = T;
+            if (qpark->hb) {
+                hb_store(qpark->hb + 1, (unsigned long long) T.batches);
+                hb_store(qpark->hb + 2, (unsigned long long) phase);
+                hb_store(qpark->hb + 5, (unsigned long long) T.chunks);
+                hb_store(qpark->hb + 6, rim_bits(T.n_start));
+                hb_store(qpark->hb + 7, rim_bits(T.delta_n));
+            }
+        }
         int batch_status = 0;
 
         // ---- 2. evaluate the requests: the only copy of the inner QAG ------------
@@ -247,6 +256,10 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
                 mask &= mask - 1;
                 const double n = readlane_d(req_n, k);
                 const int lb = wv_readlane(req_lobe, k);
+                if (lane == 0 && qpark->hb) {
+                    hb_store(qpark->hb + 8, (unsigned long long) k);
+                    hb_store(qpark->hb + 9, rim_bits(n));
+                }
                 const SymOrder so = uniform_order(sym_order(n));
                 GammaLimits L = gamma_limits(pt, n, lb);
                 L.g0 = uni(L.g0);

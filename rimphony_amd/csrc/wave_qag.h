@@ -349,7 +349,18 @@ struct WaveCounters {
 struct QagPark {
     QagState q;
     WaveCounters ctr;
+    unsigned long long *hb;   // optional heartbeat words in host-mapped memory (diagnostics), else null
 };
+
+// Diagnostics: make a word visible to the host while the kernel is still running.
+__device__ __forceinline__ void hb_store(unsigned long long *p, unsigned long long v)
+{
+#if defined(RIM_WAVE_EMU)
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
 
 // Adaptive QAG of a per-lane integrand f(x): one wave, one integral.
 // f is called once per pass with the lane's abscissa and an `active` flag and
@@ -381,6 +392,10 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
                 park->q = q;
                 park->ctr.samples += first ? 31 : 62;
                 park->ctr.steps += 1;
+                if (park->hb) {
+                    hb_store(park->hb + 3, park->ctr.steps);
+                    hb_store(park->hb + 4, (unsigned long long) q.iteration);
+                }
             }
             fv = f(x, active);
             wv_sync();

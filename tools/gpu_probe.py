@@ -21,7 +21,7 @@ def log(*a):
 
 T0 = time.time()
 faulthandler.enable(file=LOG)
-faulthandler.dump_traceback_later(90, repeat=True, file=LOG)
+
 
 import numpy as np
 import oracle_bind
@@ -33,11 +33,43 @@ L = oracle_bind.load("det")
 log("context created")
 kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", 4096)
 
+import struct
+import threading
+
+HB = ctx.heartbeat(0)
+BUSY = {"label": None, "t0": 0.0}
+
+
+def watcher():
+    last = None
+    stale = 0
+    while True:
+        time.sleep(2.0)
+        if BUSY["label"] is None:
+            last, stale = None, 0
+            continue
+        w = [int(HB[i]) for i in range(11)]
+        dec = lambda u: struct.unpack("<d", struct.pack("<Q", u))[0]
+        log("   hb[%s +%.0fs] task+1=%d batches=%d phase=%d passes=%d inner_it=%d chunks=%d n_start=%.6g delta_n=%.6g "
+            "lane=%d n=%.17g done=%d" % (BUSY["label"], time.time() - BUSY["t0"], w[0], w[1], w[2], w[3], w[4], w[5],
+                                          dec(w[6]), dec(w[7]), w[8], dec(w[9]), w[10]))
+        stale = stale + 1 if w == last else 0
+        last = w
+        if time.time() - BUSY["t0"] > 45:
+            log("   giving up on", BUSY["label"], "(stale polls: %d)" % stale)
+            LOG.flush()
+            os._exit(3)
+
+
+threading.Thread(target=watcher, daemon=True).start()
+
 
 def run(idx, m, label):
     idx = np.asarray(idx)
     t = time.time()
+    BUSY["label"], BUSY["t0"] = label, t
     out, st = ctx.compute_batch(kind, s[idx], th[idx], [p[idx] for p in params], m, want_status=True)
+    BUSY["label"] = None
     dt = time.time() - t
     w = ctx.last_work()
     log(label, "gpu done in %.3fs" % dt, "kernel ms %.2f" % ctx.last_symphony_ms(), "work", w)
