@@ -65,6 +65,23 @@ __device__ inline void load_params(const ParamPtrs &pp, size_t i, DistParams &d)
     for (int k = 0; k < 5; k++) d.par[k] = (k < NP) ? pp.p[k][i] : 0.;
 }
 
+// Fetch the next task index for the whole wave.  The two barriers are not for
+// memory ordering: they are convergent operations that pin the reconvergence
+// point of the surrounding `if (lane == 0)` regions.  Without them LLVM threads
+// the lane-0-only epilogue of one loop iteration straight into the lane-0-only
+// atomic of the next, the structurizer then builds a separate inner cycle for
+// lanes 1..63, and those lanes run ahead of lane 0, read t from their own first
+// lane (always 0) and re-execute task 0 forever (observed on gfx950, ROCm 7.2).
+__device__ __forceinline__ unsigned long long wave_next_task(unsigned long long *queue, int lane)
+{
+    __syncthreads();
+    unsigned long long t = 0;
+    if (lane == 0) t = atomicAdd(queue, 1ull);
+    __syncthreads();
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
+           (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double *norm, unsigned long long *queue)
 {
@@ -76,10 +93,7 @@ __global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
     for (;;) {
-        unsigned long long t = 0;
-        if (g.lane == 0) t = atomicAdd(queue, 1ull);
-        t = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
-            (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
+        const unsigned long long t = wave_next_task(queue, g.lane);
         if (t >= n) break;
         const size_t i = (size_t) t;
 
@@ -126,14 +140,6 @@ struct SymArgs {
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
 __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
-
-__device__ inline unsigned long long wave_next_task(unsigned long long *queue, int lane)
-{
-    unsigned long long t = 0;
-    if (lane == 0) t = atomicAdd(queue, 1ull);
-    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
-           (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
-}
 
 template <int KIND>
 __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
         } else {
             val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
         }
+        if (g.lane == 0 && s_qpark.hb) hb_store(s_qpark.hb + 11, 400ull);
         if (g.lane == 0) {
             a.out[i * 8 + slot] = val;
             if (a.status) a.status[i * 8 + slot] = st;

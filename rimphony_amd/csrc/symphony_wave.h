@@ -94,6 +94,18 @@ struct TaskState {
     QagState oq;                                  // outer QAG over n
 };
 
+__device__ __forceinline__ void task_uniformize(TaskState &T)
+{
+    T.ans = uni(T.ans); T.ni_ans = uni(T.ni_ans); T.contrib = uni(T.contrib); T.delta_n = uni(T.delta_n);
+    T.incr = uni(T.incr); T.n_start = uni(T.n_start);
+    T.dr_h = uni(T.dr_h); T.dr_r0 = uni(T.dr_r0); T.dr_err = uni(T.dr_err);
+    T.qa = uni(T.qa); T.qb = uni(T.qb);
+    T.disc_next = (long long) rim_bits(uni(rim_frombits((unsigned long long) T.disc_next)));
+    T.chunks = uni(T.chunks); T.lobe = uni(T.lobe); T.phase = uni(T.phase); T.ni_failed = uni(T.ni_failed);
+    T.status = uni(T.status); T.batches = uni(T.batches);
+    qag_uniformize(T.oq);
+}
+
 __device__ __forceinline__ SymOrder uniform_order(SymOrder so)
 {
     so.n = uni(so.n);
@@ -110,6 +122,9 @@ __device__ __forceinline__ SymOrder uniform_order(SymOrder so)
     }
     return so;
 }
+
+// diagnostics: progress marker in heartbeat word 11
+#define RIM_HB_STAGE(code) do { if (lane == 0 && qpark->hb) hb_store(qpark->hb + 11, (unsigned long long) (code)); } while (0)
 
 template <int KIND>
 __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
@@ -149,6 +164,7 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
 
     // What follows once the current lobe's n_integration has ended (symphony.rs:127-146).
     auto end_of_lobe = [&]() -> int {
+        RIM_HB_STAGE(220);
         const double c = T.ni_failed ? RIM_NAN : T.ni_ans;
         T.ans += c;
         if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; return PH_DONE; }
@@ -270,8 +286,8 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
                 QagState iq;
                 wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, iq, qpark);
                 if (lane == 0) qpark->ctr.inner_qags += 1;
-                double val = iq.result;
-                if (iq.status != QAG_SUCCESS) {
+                double val = uni(iq.result);
+                if (uni(iq.status) != QAG_SUCCESS) {
                     val = RIM_NAN;
                     batch_status |= ST_INNER_FAIL;
                     if (iq.status == QAG_ESTORE) batch_status |= ST_STORE_FULL;
@@ -282,7 +298,9 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
 
         wv_sync();
         T = *park;
-        T.status |= batch_status;
+        task_uniformize(T);
+        T.status |= uni(batch_status);
+        RIM_HB_STAGE(100 + phase);
 
         // ---- 3. continuation of the posting phase --------------------------------
         if (phase == PH_DISCRETE) {
@@ -368,8 +386,11 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
         T.ni_ans += T.contrib;
         T.n_start += T.delta_n;
         if (T.n_start > 1e13) T.incr = 1.;
+        RIM_HB_STAGE(200);
         T.phase = chunk_loop_head();
+        RIM_HB_STAGE(210 + T.phase);
     }
+    RIM_HB_STAGE(300);
 
     status_out = T.status;
     double ans = T.ans;
@@ -384,6 +405,7 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
         ans = ans * ((tpe * tpe) / (RIM_SPEED_LIGHT * acos_th));
     else
         ans = ans * (-1. * (tpe * tpe) / (2. * RIM_MASS_ELECTRON * RIM_SPEED_LIGHT * acos_th));
+    RIM_HB_STAGE(310);
     return ans;
 }
 

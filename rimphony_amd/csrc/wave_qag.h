@@ -190,6 +190,21 @@ struct QagState {
     double result, abserr;
 };
 
+// After a reload from LDS the compiler can no longer see that the state is
+// wave-uniform; passing every field through readfirstlane restores that
+// knowledge (scalar branches, SGPR residency) -- and it is what keeps the
+// cross-lane operations inside the QAG loops in provably uniform control flow.
+__device__ __forceinline__ void qag_uniformize(QagState &q)
+{
+    q.epsabs = uni(q.epsabs); q.epsrel = uni(q.epsrel); q.limit = uni(q.limit);
+    q.area = uni(q.area); q.errsum = uni(q.errsum); q.tolerance = uni(q.tolerance);
+    q.iteration = uni(q.iteration); q.rt1 = uni(q.rt1); q.rt2 = uni(q.rt2);
+    q.error_type = uni(q.error_type); q.size = uni(q.size); q.imax = uni(q.imax);
+    q.a1 = uni(q.a1); q.b1 = uni(q.b1); q.a2 = uni(q.a2); q.b2 = uni(q.b2);
+    q.r_i = uni(q.r_i); q.e_i = uni(q.e_i);
+    q.status = uni(q.status); q.result = uni(q.result); q.abserr = uni(q.abserr);
+}
+
 __device__ __forceinline__ void qag_begin(QagState &q, double epsabs, double epsrel, int limit)
 {
     q.epsabs = epsabs;
@@ -256,9 +271,9 @@ __device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane
         imax = wv_readfirstlane(bi);
     }
     q.imax = imax;
-    const double a_i = st.a[imax], b_i = st.b[imax];
-    q.r_i = st.r[imax];
-    q.e_i = st.e[imax];
+    const double a_i = uni(st.a[imax]), b_i = uni(st.b[imax]);
+    q.r_i = uni(st.r[imax]);
+    q.e_i = uni(st.e[imax]);
     q.a1 = a_i;
     q.b1 = 0.5 * (a_i + b_i);
     q.a2 = q.b1;
@@ -325,7 +340,7 @@ __device__ __forceinline__ bool qag_after_bisect(QagState &q, const IStore &st, 
     wv_sync();
     double sum = 0;
     for (int k = 0; k < q.size; k++) sum += st.r[k];
-    q.result = sum;
+    q.result = uni(sum);
     q.abserr = q.errsum;
 
     if (q.errsum <= q.tolerance) q.status = QAG_SUCCESS;
@@ -400,6 +415,7 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
             fv = f(x, active);
             wv_sync();
             q = park->q;
+            qag_uniformize(q);
         }
         if (first) {
             const double hl = 0.5 * (b - a);

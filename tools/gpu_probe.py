@@ -48,14 +48,14 @@ def watcher():
         if BUSY["label"] is None:
             last, stale = None, 0
             continue
-        w = [int(HB[i]) for i in range(11)]
+        w = [int(HB[i]) for i in range(12)]
         dec = lambda u: struct.unpack("<d", struct.pack("<Q", u))[0]
         log("   hb[%s +%.0fs] task+1=%d batches=%d phase=%d passes=%d inner_it=%d chunks=%d n_start=%.6g delta_n=%.6g "
-            "lane=%d n=%.17g done=%d" % (BUSY["label"], time.time() - BUSY["t0"], w[0], w[1], w[2], w[3], w[4], w[5],
-                                          dec(w[6]), dec(w[7]), w[8], dec(w[9]), w[10]))
+            "lane=%d n=%.17g done=%d stage=%d" % (BUSY["label"], time.time() - BUSY["t0"], w[0], w[1], w[2], w[3], w[4], w[5],
+                                          dec(w[6]), dec(w[7]), w[8], dec(w[9]), w[10], w[11]))
         stale = stale + 1 if w == last else 0
         last = w
-        if time.time() - BUSY["t0"] > 45:
+        if time.time() - BUSY["t0"] > 40:
             log("   giving up on", BUSY["label"], "(stale polls: %d)" % stale)
             LOG.flush()
             os._exit(3)
