@@ -48,7 +48,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from rimphony_amd import api, workload
+    from rimphony_amd import api, sharding, workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -73,13 +73,10 @@ def main():
     shards = []
     for st in range(total_steps):
         start = (st * P * world) % TABLE
-        idx_global = np.arange(P * world)
         _, _, s, th, params = workload.make_batch(args.config, P * world, start=start)
-        mine = idx_global % world == rank           # interleaved sharding
+        mine = sharding.shard_indices(P * world, rank, world)     # interleaved: row i -> rank i mod world
         shards.append((torch.from_numpy(s[mine]).to(dev), torch.from_numpy(th[mine]).to(dev),
                        [torch.from_numpy(p[mine]).to(dev) for p in params]))
-    gather_buf = [torch.empty((P, 8), dtype=torch.float64, device=dev) for _ in range(world)] \
-        if (distributed and rank == 0) else None
 
     def barrier():
         if distributed:
@@ -93,7 +90,7 @@ def main():
         s, th, params = shards[i]
         out, _ = ctx.compute_batch_device(kind, s, th, params, mask)
         if distributed:
-            dist.gather(out, gather_buf, dst=0)
+            sharding.gather_table(out, P * world, rank, world, dst=0)   # RCCL gather of the output table
         if record:
             kernel_ms.append(ctx.last_symphony_ms())        # HIP events on the launch stream
             samples.append(ctx.last_work()["samples"])
@@ -131,7 +128,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_bind
             L = oracle_bind.load("det")
-            cores = os.cpu_count() or 1
+            cores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
             _, _, s, th, params = workload.make_batch(args.config, args.cpu_sample, start=0)
             c0 = time.perf_counter()
             oracle_bind.batch(L, kind, s, th, params, mask, nthreads=cores)

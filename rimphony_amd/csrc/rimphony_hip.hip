@@ -445,11 +445,12 @@ static int make_param_ptrs(int kind, const double *const *d_params, ParamPtrs &p
 extern "C" int rimphony_batch_norm_device(rimphony_ctx *c, int kind, size_t n, const double *const *d_params,
                                           double *d_norm, void *stream)
 {
-    if (!c || !d_norm) return RIMPHONY_EINVAL;
+    if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;
+    if (!d_norm) return RIMPHONY_EINVAL;
     ParamPtrs pp;
     int rc = make_param_ptrs(kind, d_params, pp);
     if (rc) return rc;
-    if (n == 0) return RIMPHONY_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
     switch (kind) {
@@ -478,12 +479,12 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
                                              const double *const *d_params, uint32_t coeff_mask,
                                              double *d_out, int32_t *d_status, void *stream)
 {
-    if (!c || !d_out) return RIMPHONY_EINVAL;
-    if (n && (!d_s || !d_theta)) return RIMPHONY_EINVAL;
+    if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
+    if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
     ParamPtrs pp;
     int rc = make_param_ptrs(kind, d_params, pp);
     if (rc) return rc;
-    if (n == 0) return RIMPHONY_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
 

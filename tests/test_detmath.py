@@ -1,0 +1,92 @@
+"""Accuracy of the deterministic elementary functions (rimphony_amd/csrc/detmath.h)
+against mpmath: they replace libm/ocml on BOTH sides of the parity tests, so they
+are pinned here independently (<= 1.5 ulp)."""
+import ctypes
+import math
+import os
+import subprocess
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = r'''
+#include "detmath.h"
+double t_exp(double x){return rim_exp(x);}
+double t_log(double x){return rim_log(x);}
+double t_log10(double x){return rim_log10(x);}
+double t_pow(double x,double y){return rim_pow(x,y);}
+double t_lgamma(double x){return rim_lgamma_pos(x);}
+double t_sin(double x){double s,c;rim_sincos(x,&s,&c);return s;}
+double t_cos(double x){double s,c;rim_sincos(x,&s,&c);return c;}
+'''
+
+
+@pytest.fixture(scope="module")
+def dm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dm")
+    c = d / "dm.c"
+    c.write_text(SRC)
+    so = d / "dm.so"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-msse4.1", "-fPIC", "-shared",
+                    "-I", os.path.join(ROOT, "rimphony_amd", "csrc"), str(c), "-o", str(so), "-lm"], check=True)
+    L = ctypes.CDLL(str(so))
+    for n in ("t_exp", "t_log", "t_log10", "t_lgamma", "t_sin", "t_cos"):
+        getattr(L, n).restype = ctypes.c_double
+        getattr(L, n).argtypes = [ctypes.c_double]
+    L.t_pow.restype = ctypes.c_double
+    L.t_pow.argtypes = [ctypes.c_double] * 2
+    return L
+
+
+def ulp_err(got, exact):
+    e = float(exact)
+    if e == 0:
+        return abs(got)
+    return float(abs(mp.mpf(got) - exact) / mp.mpf(math.ulp(e)))
+
+
+def worst(f, ref, xs):
+    return max(ulp_err(f(float(x)), ref(mp.mpf(float(x)))) for x in xs)
+
+
+def test_exp_log(dm):
+    mp.mp.prec = 200
+    rng = np.random.default_rng(1)
+    assert worst(dm.t_exp, mp.exp, np.concatenate([rng.uniform(-700, 700, 1500), rng.uniform(-1, 1, 500)])) < 1.0
+    assert worst(dm.t_log, mp.log, np.concatenate([np.exp(rng.uniform(-700, 700, 1500)), rng.uniform(0.5, 2, 500)])) < 0.6
+    assert worst(dm.t_log10, mp.log10, np.concatenate([np.exp(rng.uniform(-700, 700, 1500)), rng.uniform(0.5, 2, 500)])) < 0.6
+    assert dm.t_exp(0.0) == 1.0 and dm.t_log(1.0) == 0.0 and dm.t_log10(1000.0) == 3.0
+    assert dm.t_exp(800.0) == math.inf and dm.t_exp(-800.0) == 0.0
+    assert math.isnan(dm.t_log(-1.0)) and dm.t_log(0.0) == -math.inf
+
+
+def test_pow(dm):
+    mp.mp.prec = 200
+    rng = np.random.default_rng(2)
+    w = 0.0
+    for i in range(3000):
+        if i < 1000:
+            x, y = float(np.exp(rng.uniform(0, math.log(1e12)))), float(rng.uniform(-5, 0))
+        elif i < 2000:
+            x, y = float(rng.uniform(0, 1)), float(rng.uniform(0, 3))
+        else:
+            x, y = float(np.exp(rng.uniform(0, math.log(1e15)))), 1 / 3
+        w = max(w, ulp_err(dm.t_pow(x, y), mp.power(mp.mpf(x), mp.mpf(y))))
+    assert w < 1.5
+    assert dm.t_pow(2, 10) == 1024.0 and dm.t_pow(-2, 3) == -8.0 and math.isnan(dm.t_pow(-2, 0.5))
+    assert dm.t_pow(0, 2) == 0.0 and dm.t_pow(0, -1) == math.inf and dm.t_pow(0.0, 0.0) == 1.0
+
+
+def test_lgamma_sincos(dm):
+    mp.mp.prec = 200
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([np.exp(rng.uniform(math.log(30), math.log(1e15), 1500)), rng.uniform(16, 100, 500)])
+    assert worst(dm.t_lgamma, mp.loggamma, xs) < 0.8
+    # small arguments: absolute accuracy is what the 2F1 normalisation needs
+    for x in (1.0, 1.5, 2.0, 2.5, 3.0, 0.7, 4.3):
+        assert abs(dm.t_lgamma(x) - float(mp.loggamma(x))) < 5e-15
+    th = np.concatenate([rng.uniform(-4, 4, 1500), rng.uniform(-1e5, 1e5, 1500), rng.uniform(0, 1.6, 1000)])
+    assert worst(dm.t_sin, mp.sin, th) < 1.5
+    assert worst(dm.t_cos, mp.cos, th) < 1.5

@@ -1,0 +1,191 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol
+the header declares, the host build of the scalar device functions matches the
+oracle bit for bit, the workload generator is deterministic, and the interleaved
+shard / gather logic of the multi-GPU path works (gloo, world_size 2)."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_bind
+from rimphony_amd import _build, workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    _build.build_hip()
+    hdr = open(os.path.join(ROOT, "include", "rimphony_hip.h")).read()
+    names = set(re.findall(r"\b(rimphony_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"rimphony_ctx"}
+    assert len(names) >= 13
+    lib = ctypes.CDLL(os.path.join(ROOT, "rimphony_amd", "librimphony_hip.so"))
+    for n in sorted(names):
+        assert hasattr(lib, n), "missing export: " + n
+    from rimphony_amd import capi
+    assert set(capi.SYMBOLS) <= names
+    lib.rimphony_dist_nparams.restype = ctypes.c_int
+    assert [lib.rimphony_dist_nparams(k) for k in range(4)] == [4, 1, 5, 4]
+    assert lib.rimphony_dist_nparams(7) < 0
+    lib.rimphony_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.rimphony_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rimphony_amd import api, capi
+    with pytest.raises(capi.RimphonyError):
+        api.Context(0)
+    # the raw C entry point refuses as well
+    lib = capi.load()
+    h = ctypes.c_void_p()
+    assert lib.rimphony_ctx_create(0, ctypes.byref(h)) == -4   # RIMPHONY_ENODEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must never include / import / link / load the oracle
+    (comments may cite oracle files as documentation)."""
+    pat = re.compile(r'#\s*include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|liboracle|oracle_bind|dlopen')
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rimphony_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")) and f != "_build.py":
+                # _build.build_oracle() compiles the checker for the tests; it does not load it
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(txt), f
+    assert not pat.search(open(os.path.join(ROOT, "include", "rimphony_hip.h")).read())
+    # and the shared library has no dependency on it
+    out = subprocess.run(["ldd", os.path.join(ROOT, "rimphony_amd", "librimphony_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+@pytest.fixture(scope="module")
+def devh():
+    so = _build.build_test_support()
+    D = ctypes.CDLL(so)
+    D.devh_bessel_j.restype = ctypes.c_double; D.devh_bessel_j.argtypes = [ctypes.c_double] * 2
+    D.devh_bessel_dj.restype = ctypes.c_double; D.devh_bessel_dj.argtypes = [ctypes.c_double] * 2
+    D.devh_gamma_integrand.restype = ctypes.c_double
+    D.devh_gamma_integrand.argtypes = [ctypes.c_int] * 3 + [ctypes.c_double] * 3 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_double] * 3
+    return D
+
+
+def _same(a, b):
+    return a == b or (a != a and b != b)
+
+
+def test_device_bessel_host_build_bit_exact(devh, oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(20000):
+        u = rng.random()
+        n = float(rng.integers(0, 31)) if u < 0.2 else float(np.exp(rng.uniform(math.log(30), math.log(1e14))))
+        if rng.random() < 0.5 and n >= 1:
+            n = float(math.floor(n))
+        x = n * (1 - 10 ** rng.uniform(-12, 0)) if rng.random() < 0.9 else n * (1 + 10 ** rng.uniform(-12, -3))
+        if rng.random() < 0.02:
+            x = n
+        assert _same(oracle.rimo_bessel_j(n, x), devh.devh_bessel_j(n, x)), (n, x)
+        assert _same(oracle.rimo_bessel_dj(n, x), devh.devh_bessel_dj(n, x)), (n, x)
+
+
+def test_device_integrand_host_build_bit_exact(devh, oracle):
+    rng = np.random.default_rng(8)
+    gen = {0: lambda: [rng.uniform(1.5, 4), float(np.exp(rng.uniform(0, math.log(30)))), 1e12, 1e10],
+           1: lambda: [float(np.exp(rng.uniform(math.log(.1), math.log(100))))],
+           2: lambda: [rng.uniform(1.5, 4), rng.uniform(0, 3), 1., 1e12, 1e10],
+           3: lambda: [rng.uniform(1.5, 4.5), float(np.exp(rng.uniform(1, 3))), rng.uniform(0, 3), 1e10]}
+    for i in range(4000):
+        kind = i % 4
+        par = gen[kind]()
+        d, st = oracle_bind.mkdist(oracle, kind, par)
+        s = float(np.exp(rng.uniform(math.log(.1), math.log(1e7))))
+        th = float(rng.uniform(0.003, 1.57))
+        sn, cs = math.sin(th), math.cos(th)
+        # the oracle computes sin/cos with detmath; take them from its own gamma_integrand path by
+        # passing theta and comparing through the public function
+        n = s * abs(sn) + 1 + float(np.exp(rng.uniform(-3, 12)))
+        if rng.random() < 0.5:
+            n = float(math.floor(n))
+        nos = n / s
+        root = math.sqrt(max(nos * nos - sn * sn, 0))
+        gm, gp = (nos - abs(cs) * root) / sn ** 2, (nos + abs(cs) * root) / sn ** 2
+        g = gm + (gp - gm) * rng.random()
+        co, stk = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+        a = oracle.rimo_gamma_integrand(d, co, stk, s, th, n, g)
+        # detmath sincos of theta, as the kernels do
+        import test_detmath  # noqa: F401  (keeps the helper build next to this test)
+        sv, cv = _detsincos(th)
+        pa = (ctypes.c_double * 5)(*(par + [0.] * 5)[:5])
+        b = devh.devh_gamma_integrand(kind, co, stk, s, cv, sv, pa, d.norm, n, g)
+        assert _same(a, b), (kind, par, s, th, n, g, a, b)
+
+
+_SC = {}
+
+
+def _detsincos(x):
+    if "lib" not in _SC:
+        so = _build.build_test_support()
+        L = ctypes.CDLL(so)
+        L.devh_sincos.restype = None
+        L.devh_sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        _SC["lib"] = L
+    s, c = ctypes.c_double(), ctypes.c_double()
+    _SC["lib"].devh_sincos(x, ctypes.byref(s), ctypes.byref(c))
+    return s.value, c.value
+
+
+def test_workload_is_deterministic_and_in_range():
+    k1, m1, s1, t1, p1 = workload.make_batch("cfg2_powerlaw_jI_aI", 1000)
+    k2, m2, s2, t2, p2 = workload.make_batch("cfg2_powerlaw_jI_aI", 500, start=500)
+    assert (s1[500:] == s2).all() and (t1[500:] == t2).all() and all((a[500:] == b).all() for a, b in zip(p1, p2))
+    assert s1.min() >= 0.1 and s1.max() <= 1e4 and t1.min() >= 0.05 and t1.max() <= 1.52
+    assert p1[0].min() >= 1.5 and p1[0].max() <= 4 and p1[1].min() >= 1 and p1[1].max() <= 30
+    assert m1 == 0x03 and k1 == 0
+    for cfg in workload.CONFIGS:
+        kind, mask, s, th, params = workload.make_batch(cfg, 16)
+        assert len(params) == [4, 1, 5, 4][kind]
+    # splitmix64 reference value: first output for seed 0 is 0xE220A8397B1DCDAF
+    with np.errstate(over="ignore"):
+        assert int(workload.splitmix64(np.uint64(0))) == 0xE220A8397B1DCDAF
+
+
+def test_interleaved_shard_and_gather_gloo_world2(tmp_path):
+    """The N>1 path of bench.py / rimphony_amd.sharding on CPU: 2 ranks, gloo, the per-rank
+    compute replaced by the oracle (test infrastructure).  The gathered table must equal the
+    single-process table bit for bit."""
+    script = tmp_path / "w2.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_bind
+from rimphony_amd import workload, sharding
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+L = oracle_bind.load("det")
+kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", 10)   # ragged: 10 rows over 2 ranks... plus 1 more below
+kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", 11)
+idx = sharding.shard_indices(11, rank, world)
+local = oracle_bind.batch(L, kind, s[idx], th[idx], [p[idx] for p in params], mask, nthreads=2)
+table = sharding.gather_table(torch.from_numpy(local), 11, rank, world, dst=0)
+if rank == 0:
+    ref = oracle_bind.batch(L, kind, s, th, params, mask, nthreads=2)
+    t = table.numpy()
+    same = (t.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(t) & np.isnan(ref))
+    assert same.all()
+    print("OK")
+dist.destroy_process_group()
+''' % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "OK" in r.stdout
