@@ -1,0 +1,178 @@
+// rimphony.hpp -- C++ host-side mirror of rimphony's public API over the C ABI of
+// include/rimphony_hip.h (header-only).  The reference's host language is Rust,
+// which this image lacks; this header keeps the same names, argument meaning and
+// error behaviour so a user of the crate finds what they expect:
+//
+//   enum Stokes / Coefficient                                   lib.rs:74-107
+//   trait SynchrotronCalculator { compute_dimensionless, compute_cgs,
+//       compute_all_dimensionless, compute_all_cgs }           lib.rs:150-210
+//   PowerLawDistribution::new(p).gamma_limits(..).full_calculation(..)   power_law.rs:71-111
+//   ThermalJuettnerDistribution::new(t).full_calculation(..)             thermal_juettner.rs:45-72
+//   PitchyPowerLawDistribution::new(p,k).gamma_limits(..)...             pitchy_pl.rs:73-115
+//   PitchyKappaDistribution::new(kappa,width,k).gamma_cutoff(..)...      pitchy_kappa.rs:70-125
+//
+// plus the batched entry the GPU path exists for: BatchCalculator::compute().
+// Numerical failure is NaN, never an exception (symphony.rs:115-117); API misuse
+// and HIP errors throw std::runtime_error.  No CPU fallback.
+#ifndef RIMPHONY_HPP
+#define RIMPHONY_HPP
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rimphony_hip.h"
+
+namespace rimphony {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double TWO_PI = 2. * PI;
+constexpr double MASS_ELECTRON = 9.1093826e-28;
+constexpr double SPEED_LIGHT = 2.99792458e10;
+constexpr double ELECTRON_CHARGE = 4.80320680e-10;
+
+enum class Stokes { I = 0, Q = 1, V = 2 };
+enum class Coefficient { Emission = 0, Absorption = 1, Faraday = 2 };
+
+inline void check(int rc, const char *what)
+{
+    if (rc != RIMPHONY_OK) throw std::runtime_error(std::string(what) + ": " + rimphony_strerror(rc));
+}
+
+class Context {
+public:
+    explicit Context(int device = 0) { check(rimphony_ctx_create(device, &ctx_), "rimphony_ctx_create"); }
+    ~Context() { rimphony_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    rimphony_ctx *get() const { return ctx_; }
+private:
+    rimphony_ctx *ctx_ = nullptr;
+};
+
+// slot order of compute_all_dimensionless (lib.rs:176-177)
+inline int slot_of(Coefficient c, Stokes s)
+{
+    if (c == Coefficient::Faraday) return s == Stokes::Q ? 6 : s == Stokes::V ? 7 : -1;
+    return 2 * static_cast<int>(s) + static_cast<int>(c);
+}
+
+// N x (full_calculation + compute_all_dimensionless): host SoA arrays in, [n][8] out.
+class BatchCalculator {
+public:
+    BatchCalculator(std::shared_ptr<Context> ctx, int dist_kind) : ctx_(std::move(ctx)), kind_(dist_kind)
+    {
+        if (rimphony_dist_nparams(kind_) < 0) throw std::runtime_error("unknown distribution kind");
+    }
+    std::vector<double> compute(const std::vector<double> &s, const std::vector<double> &theta,
+                                const std::vector<std::vector<double>> &params, uint32_t mask = RIMPHONY_SLOTS_ALL,
+                                std::vector<int32_t> *status = nullptr) const
+    {
+        const size_t n = s.size();
+        if (theta.size() != n || static_cast<int>(params.size()) != rimphony_dist_nparams(kind_))
+            throw std::runtime_error("compute: array shapes do not match");
+        std::vector<const double *> pp;
+        for (const auto &p : params) {
+            if (p.size() != n) throw std::runtime_error("compute: parameter array length");
+            pp.push_back(p.data());
+        }
+        std::vector<double> out(n * 8, std::numeric_limits<double>::quiet_NaN());
+        if (status) status->assign(n * 8, 0);
+        check(rimphony_batch_compute(ctx_->get(), kind_, n, s.data(), theta.data(), pp.data(), mask, out.data(),
+                                     status ? status->data() : nullptr), "rimphony_batch_compute");
+        return out;
+    }
+private:
+    std::shared_ptr<Context> ctx_;
+    int kind_;
+};
+
+// trait SynchrotronCalculator for one parameter point (each call is a 1-point batch)
+class FullSynchrotronCalculator {
+public:
+    FullSynchrotronCalculator(std::shared_ptr<Context> ctx, int kind, std::vector<double> params)
+        : batch_(std::move(ctx), kind), params_(std::move(params)) {}
+
+    double compute_dimensionless(Coefficient coeff, Stokes stokes, double s, double theta) const
+    {
+        const int k = slot_of(coeff, stokes);
+        if (k < 0) return std::numeric_limits<double>::quiet_NaN();    // (Faraday, I): lib.rs:239-240
+        return run(s, theta, 1u << k)[k];
+    }
+    double compute_cgs(Coefficient coeff, Stokes stokes, double nu, double b, double n_e, double theta) const
+    {
+        const double nu_c = ELECTRON_CHARGE * b / (TWO_PI * MASS_ELECTRON * SPEED_LIGHT);
+        const double val = compute_dimensionless(coeff, stokes, nu / nu_c, theta);
+        return coeff == Coefficient::Emission ? val * n_e * nu : val * n_e / nu;
+    }
+    std::array<double, 8> compute_all_dimensionless(double s, double theta) const
+    {
+        const auto v = run(s, theta, RIMPHONY_SLOTS_ALL);
+        std::array<double, 8> rv;
+        for (int k = 0; k < 8; k++) rv[k] = v[k];
+        return rv;
+    }
+    std::array<double, 8> compute_all_cgs(double nu, double b, double n_e, double theta) const
+    {
+        const double nu_c = ELECTRON_CHARGE * b / (TWO_PI * MASS_ELECTRON * SPEED_LIGHT);
+        auto rv = compute_all_dimensionless(nu / nu_c, theta);
+        for (int k = 0; k < 8; k++) rv[k] = (k == 0 || k == 2 || k == 4) ? rv[k] * n_e * nu : rv[k] * n_e / nu;
+        return rv;
+    }
+private:
+    std::vector<double> run(double s, double theta, uint32_t mask) const
+    {
+        std::vector<std::vector<double>> pp;
+        for (double p : params_) pp.push_back({p});
+        return batch_.compute({s}, {theta}, pp, mask);
+    }
+    BatchCalculator batch_;
+    std::vector<double> params_;
+};
+
+class PowerLawDistribution {
+public:
+    explicit PowerLawDistribution(double p) : p_(p) {}
+    PowerLawDistribution &gamma_limits(double gmin, double gmax, double gcut) { gmin_ = gmin; gmax_ = gmax; gcut_ = gcut; return *this; }
+    FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
+    { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_POWER_LAW, {p_, gmin_, gmax_, gcut_}); }
+private:
+    double p_, gmin_ = 1., gmax_ = 1e12, gcut_ = 1e10;     // defaults: power_law.rs:71-79
+};
+
+class ThermalJuettnerDistribution {
+public:
+    explicit ThermalJuettnerDistribution(double t) : t_(t) {}
+    FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
+    { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_THERMAL_JUETTNER, {t_}); }
+private:
+    double t_;
+};
+
+class PitchyPowerLawDistribution {
+public:
+    PitchyPowerLawDistribution(double p, double k) : p_(p), k_(k) {}
+    PitchyPowerLawDistribution &gamma_limits(double gmin, double gmax, double gcut) { gmin_ = gmin; gmax_ = gmax; gcut_ = gcut; return *this; }
+    FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
+    { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_PITCHY_PL, {p_, k_, gmin_, gmax_, gcut_}); }
+private:
+    double p_, k_, gmin_ = 1., gmax_ = 1e12, gcut_ = 1e10;
+};
+
+class PitchyKappaDistribution {
+public:
+    PitchyKappaDistribution(double kappa, double width, double k) : kappa_(kappa), width_(width), k_(k) {}
+    PitchyKappaDistribution &gamma_cutoff(double gcut) { gcut_ = gcut; return *this; }
+    FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
+    { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_PITCHY_KAPPA, {kappa_, width_, k_, gcut_}); }
+private:
+    double kappa_, width_, k_, gcut_ = 1e10;
+};
+
+}  // namespace rimphony
+#endif
