@@ -96,9 +96,12 @@ const char *rimphony_version(void);
  * counts, read back synchronously): integrand samples, wave-wide evaluation
  * passes, inner QAG calls. */
 typedef struct {
-    uint64_t samples;
+    uint64_t samples;               /* Symphony kernel */
     uint64_t passes;
     uint64_t inner_qags;
+    uint64_t faraday_samples;       /* Heyvaerts kernel */
+    uint64_t faraday_passes;
+    uint64_t faraday_inner_qags;
 } rimphony_work;
 int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
 
@@ -114,7 +117,8 @@ int rimphony_last_symphony_ms(rimphony_ctx *ctx, float *ms);
  * (examples/crank-out-pitchykappa.rs:193-200).  Words: [0] task+1, [1] batches,
  * [2] phase, [3] integrand passes, [4] inner QAG iteration, [5] chunks,
  * [6] n_start bits, [7] delta_n bits, [8] lane of the running gamma-integral,
- * [9] its n (bits), [10] 1 when the task has finished. */
+ * [9] its n (bits), [10] 1 when the task has finished.  Tasks of the Heyvaerts kernel
+ * are addressed as task | (1 << 62). */
 int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_words);
 
 /* The batched compute(): N x (full_calculation + compute_all_dimensionless).

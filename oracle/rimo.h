@@ -104,6 +104,12 @@ double rimo_bessel_j(double n, double x);   /* pkgw_bessel_j  bessel.c:318-376 *
 double rimo_bessel_dj(double n, double x);  /* pkgw_bessel_dj bessel.c:379-405 */
 double rimo_bessel_jn_int(int n, double x); /* stands in for gsl_sf_bessel_Jn  */
 
+/* --- special functions behind heyvaerts.rs (special-fun crate in the reference) --- */
+double rimo_gamma_real(double z);
+double rimo_bessel_i(double nu, double x);     /* x.besseli(nu)  */
+double rimo_bessel_jnu(double nu, double x);   /* x.besselj(nu), ascending series (small x) */
+double rimo_bessel_ynu(double nu, double x);   /* x.bessely(nu), reflection formula */
+
 /* --- distributions ----------------------------------------------------- */
 int rimo_dist_init(rimo_dist *d, int kind, const double *params); /* new()+limits+full_calculation(): 0 or GSL status */
 double rimo_calc_f(const rimo_dist *d, double gamma, double cos_xi);
@@ -115,6 +121,8 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
 double rimo_compute_dimensionless(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c);
 void rimo_compute_all_dimensionless(const rimo_dist *d, double s, double theta, double out[8], rimo_counters *c);
 double rimo_compute_cgs(const rimo_dist *d, int coeff, int stokes, double nu, double b, double n_e, double theta);
+
+double rimo_hey_element(const rimo_dist *d, int stokes, double s, double theta, int qr, double fixed, double v);
 
 /* diagnostics (lib.rs:254-298) */
 double rimo_gamma_integrand(const rimo_dist *d, int coeff, int stokes, double s, double theta, double n, double gamma);

@@ -128,7 +128,9 @@ class Context:
     def last_work(self):
         w = capi.Work()
         capi.check(self.lib.rimphony_last_work(self.handle, ctypes.byref(w)), "rimphony_last_work")
-        return {"samples": int(w.samples), "passes": int(w.passes), "inner_qags": int(w.inner_qags)}
+        return {"samples": int(w.samples), "passes": int(w.passes), "inner_qags": int(w.inner_qags),
+                "faraday_samples": int(w.faraday_samples), "faraday_passes": int(w.faraday_passes),
+                "faraday_inner_qags": int(w.faraday_inner_qags)}
 
     def last_symphony_ms(self):
         ms = ctypes.c_float()

@@ -23,7 +23,8 @@ class RimphonyError(RuntimeError):
 
 
 class Work(ctypes.Structure):
-    _fields_ = [("samples", c_uint64), ("passes", c_uint64), ("inner_qags", c_uint64)]
+    _fields_ = [("samples", c_uint64), ("passes", c_uint64), ("inner_qags", c_uint64),
+                ("faraday_samples", c_uint64), ("faraday_passes", c_uint64), ("faraday_inner_qags", c_uint64)]
 
 
 _lib = None

@@ -1,0 +1,222 @@
+// dev_heyvaerts.h -- per-sample device functions of the Heyvaerts Faraday path.
+//
+//   fill_coord_vars                      heyvaerts.rs:194-201
+//   h_qr / h_nr / f_qr / f_nr elements   heyvaerts.rs:302-468
+//   dfdsigma                             heyvaerts.rs:472-493
+//   special_fun::FloatSpecial::{besseli, besselj, bessely}   call sites heyvaerts.rs:331-364, 437-441
+//
+// The Bessel functions come from an un-vendored crate in the reference; they are
+// evaluated here from their ascending series (see oracle/rimo_heyvaerts.c for why
+// that covers every argument the path can produce).  The Gamma-function
+// prefactors of the four fixed fractional orders are computed once per task
+// (HeyConsts) instead of once per sample.  Operation order matches
+// oracle/rimo_heyvaerts.c exactly (bit-for-bit parity is tested).
+#ifndef RIM_DEV_HEYVAERTS_H
+#define RIM_DEV_HEYVAERTS_H
+
+#include "dev_symphony.h"
+
+namespace rim {
+
+#define RIM_FOUR_OVER_SQRT_27 0.769800358919501
+#define RIM_INVERSE_C (1. / 2.99792458e10)
+#define RIM_INVERSE_SQRT_3 0.5773502691896257
+#define RIM_SQRT_8_OVER_3 0.9428090415820635
+#define RIM_THREE_TWO_THIRDS 2.080083823051904
+#define RIM_G_APPROXIMATION_CUTOFF 10.
+
+// Rust f64::min / f64::max (a NaN operand is ignored)
+RIM_DEV double rust_min(double a, double b) { if (a != a) return b; if (b != b) return a; return a < b ? a : b; }
+RIM_DEV double rust_max(double a, double b) { if (a != a) return b; if (b != b) return a; return a > b ? a : b; }
+
+RIM_DEV double gamma_real(double z)
+{
+    double prod = 1., w = z;
+    int guard = 0;
+    while (w < 16. && guard < 64) { prod = prod * w; w = w + 1.; guard++; }
+    return rim_exp(rim_lgamma_stirling(w)) / prod;
+}
+
+RIM_DEV double ascending_series(double nu, double q, double sign)
+{
+    double term = 1., sum = 1.;
+    for (int k = 1; k <= 500; k++) {
+        term = term * (sign * q / (k * (k + nu)));
+        sum = sum + term;
+        if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
+    }
+    return sum;
+}
+
+// I_nu(x) with Gamma(nu + 1) supplied
+RIM_DEV double bessel_i_g(double nu, double gam, double x)
+{
+    const double h = 0.5 * x;
+    return rim_pow(h, nu) / gam * ascending_series(nu, h * h, 1.);
+}
+
+RIM_DEV double bessel_jnu(double nu, double x)
+{
+    const double h = 0.5 * x;
+    return rim_pow(h, nu) / gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);
+}
+
+RIM_DEV double bessel_ynu(double nu, double x)
+{
+    double sn, cs;
+    if (nu == rim_floor(nu)) nu = nu + 1.4901161193847656e-08 * (rim_fabs(nu) > 1. ? rim_fabs(nu) : 1.);
+    rim_sincos(RIM_PI * nu, &sn, &cs);
+    return (cs * bessel_jnu(nu, x) - bessel_jnu(-nu, x)) / sn;
+}
+
+// Per-task constants: Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3.
+struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; };
+
+RIM_DEV HeyConsts hey_consts()
+{
+    HeyConsts c;
+    c.g_p23 = gamma_real(2. / 3. + 1.);
+    c.g_m23 = gamma_real(-2. / 3. + 1.);
+    c.g_p13 = gamma_real(1. / 3. + 1.);
+    c.g_m13 = gamma_real(-1. / 3. + 1.);
+    return c;
+}
+
+// Observer data of one Faraday coefficient (wave-uniform)
+struct HeyPoint {
+    double s, cos_th, sin_th, sigma0, sigma0_sq;
+    int stokes;
+};
+
+struct HeyCoord { double sigma, pomega, x, gamma, mu; };
+
+RIM_DEV HeyCoord fill_coord_vars(const HeyPoint &pt, double sigma, double pomega)
+{
+    HeyCoord c;
+    c.sigma = sigma;
+    c.pomega = pomega;
+    c.x = rim_sqrt(sigma * sigma - pomega * pomega - pt.sigma0_sq);
+    c.gamma = (sigma - pomega * pt.cos_th) / (pt.sigma0 * pt.sin_th);
+    c.mu = (sigma * pt.cos_th - pomega) / (pt.sigma0 * pt.sin_th * rim_sqrt(c.gamma * c.gamma - 1.));
+    return c;
+}
+
+template <int KIND>
+RIM_DEV double dfdsigma(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
+{
+    double dfdg, dfdcxi;
+    calc_f_derivatives<KIND>(d, c.gamma, c.mu, dfdg, dfdcxi);
+    const double g_term = dfdg / (pt.sigma0 * pt.sin_th);
+    double mu_term;
+    if (dfdcxi == 0.) {
+        mu_term = 0.;
+    } else {
+        const double q = c.sigma - c.pomega * pt.cos_th;
+        const double r = c.pomega - c.sigma * pt.cos_th;
+        const double t = pt.sigma0 * pt.sin_th;
+        const double u = q * q - t * t;
+        const double dcxi_dsigma = (q * u * pt.cos_th + u * r + r * (t * t)) / (rim_pow(u, 1.5) * q);
+        mu_term = dcxi_dsigma * dfdcxi;
+    }
+    return g_term + mu_term;
+}
+
+template <int KIND>
+RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, const HeyCoord &c)
+{
+    const double po_sq = c.pomega * c.pomega;
+    const double smxox = (c.sigma - c.x) / c.x;
+    const double g = RIM_SQRT_8_OVER_3 * rim_pow(c.sigma - c.x, 1.5) / rim_sqrt(c.x);
+    double y1, y2;
+    if (g < RIM_G_APPROXIMATION_CUTOFF) {
+        const double plus = bessel_i_g(2. / 3., hc.g_p23, g);
+        const double minus = bessel_i_g(-2. / 3., hc.g_m23, g);
+        y1 = RIM_FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
+        const double plus1 = bessel_i_g(1. / 3., hc.g_p13, g);
+        const double minus1 = bessel_i_g(-1. / 3., hc.g_m13, g);
+        y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
+    } else {
+        const double js = bessel_jnu(c.sigma, c.x);
+        const double ys = bessel_ynu(c.sigma, c.x);
+        const double jvp = bessel_jnu(c.sigma - 1., c.x) - c.sigma * js / c.x;
+        const double yvp = bessel_ynu(c.sigma - 1., c.x) - c.sigma * ys / c.x;
+        y1 = jvp * yvp;
+        y2 = -js * ys;
+    }
+    const double t1 = RIM_PI * RIM_PI * (c.x * c.x) * y1;
+    const double t2 = RIM_PI * RIM_PI * (c.pomega * c.pomega) * y2;
+    const double t3 = -RIM_PI * (2. * po_sq + pt.sigma0_sq) / rim_sqrt(po_sq + pt.sigma0_sq);
+    const double dfds = dfdsigma<KIND>(pt, d, c);
+    return RIM_INVERSE_C * (t1 + t2 + t3) * dfds;
+}
+
+RIM_DEV void nr_common(const HeyCoord &c, double &a1, double &a2, double &xa1p, double &ssqmxsq, double &x_sq)
+{
+    const double s_sq = c.sigma * c.sigma;
+    x_sq = c.x * c.x;
+    ssqmxsq = s_sq - x_sq;
+    const double ratio = s_sq / ssqmxsq;
+    a1 = 1. / 8. - 5. / 24. * s_sq / ssqmxsq;
+    a2 = 3. / 128. - 77. / 576. * s_sq / ssqmxsq + 385. / 3456. * (ratio * ratio);
+    xa1p = -5. / 12. * s_sq * x_sq / (ssqmxsq * ssqmxsq);
+}
+
+template <int KIND>
+RIM_DEV double h_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
+{
+    double a1, a2, xa1p, ssqmxsq, x_sq;
+    nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
+    const double t1 = (6. * a2 - a1 * a1 + xa1p) / rim_sqrt(ssqmxsq) + a1 * x_sq / rim_pow(ssqmxsq, 1.5)
+        - (x_sq * x_sq) / rim_pow(ssqmxsq, 2.5) / 8.;
+    const double t2 = (6. * a2 - a1 * a1) / rim_pow(ssqmxsq, 1.5);
+    const double u1 = 2. * t1 - pt.sigma0_sq * t2;
+    const double dfds = dfdsigma<KIND>(pt, d, c);
+    return RIM_PI * RIM_INVERSE_C * u1 * dfds;
+}
+
+template <int KIND>
+RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, const HeyCoord &c)
+{
+    const double g = RIM_SQRT_8_OVER_3 * rim_pow(c.sigma - c.x, 1.5) / rim_sqrt(c.x);
+    double y;
+    if (g < RIM_G_APPROXIMATION_CUTOFF) {
+        y = RIM_INVERSE_SQRT_3
+            * g
+            * (bessel_i_g(-2. / 3., hc.g_m23, g) - bessel_i_g(2. / 3., hc.g_p23, g))
+            * (bessel_i_g(-1. / 3., hc.g_m13, g) + bessel_i_g(1. / 3., hc.g_p13, g));
+    } else {
+        const double jvp = bessel_jnu(c.sigma - 1., c.x) - c.sigma * bessel_jnu(c.sigma, c.x) / c.x;
+        y = -c.x * jvp * bessel_ynu(c.sigma, c.x);
+    }
+    const double dfds = dfdsigma<KIND>(pt, d, c);
+    return -(2. * RIM_PI) * RIM_INVERSE_C * c.pomega * (RIM_PI * y - 1.) * dfds;
+}
+
+template <int KIND>
+RIM_DEV double f_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
+{
+    double a1, a2, xa1p, ssqmxsq, x_sq;
+    nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
+    const double z =
+        0.5 * x_sq / rim_pow(ssqmxsq, 1.5)
+        + (6. * a2 + xa1p - a1 * a1) / ssqmxsq
+        + 1.5 * a1 * x_sq / (ssqmxsq * ssqmxsq);
+    const double dfds = dfdsigma<KIND>(pt, d, c);
+    return -2. * RIM_PI * RIM_INVERSE_C * z * c.pomega * dfds;
+}
+
+// The inner integrand of either regime: `qr` selects quasi-resonant (integration variable
+// pomega at fixed sigma) or non-resonant (integration variable sigma at fixed pomega).
+template <int KIND>
+RIM_DEV double hey_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, bool qr, double fixed, double v)
+{
+    if (qr) {
+        const HeyCoord c = fill_coord_vars(pt, fixed, v);
+        return pt.stokes == STOKES_Q ? h_qr_element<KIND>(pt, d, hc, c) : f_qr_element<KIND>(pt, d, hc, c);
+    }
+    const HeyCoord c = fill_coord_vars(pt, v, fixed);
+    return pt.stokes == STOKES_Q ? h_nr_element<KIND>(pt, d, c) : f_nr_element<KIND>(pt, d, c);
+}
+
+}  // namespace rim
+#endif

@@ -17,6 +17,7 @@
 
 #include "../../include/rimphony_hip.h"
 #include "symphony_wave.h"
+#include "heyvaerts_wave.h"
 
 using namespace rim;
 
@@ -210,6 +211,81 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------
+// heyvaerts (Faraday rho_Q = slot 6, rho_V = slot 7)
+// ------------------------------------------------------------------------------
+
+template <int KIND>
+__global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
+    __shared__ HeyTask s_park;
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore inner = istore_carve(s_inner, CAP_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
+
+    HeyConsts hc = hey_consts();
+    hc.g_p23 = uni(hc.g_p23); hc.g_m23 = uni(hc.g_m23); hc.g_p13 = uni(hc.g_p13); hc.g_m13 = uni(hc.g_m13);
+
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
+    for (;;) {
+        const unsigned long long t = wave_next_task(a.queue + 4, g.lane);
+        if (t >= ntasks) break;
+        const size_t i = (size_t) (t / (unsigned) a.nslots);
+        const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
+
+        HeyPoint pt;
+        pt.s = uni(a.s[i]);
+        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
+        pt.sin_th = uni(pt.sin_th);
+        pt.cos_th = uni(pt.cos_th);
+        pt.sigma0 = uni(pt.s * pt.sin_th);
+        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
+        pt.stokes = uni(c_slot_stokes[slot]);
+
+        DistParams d;
+        load_params<KIND>(a.pp, i, d);
+        const double norm = uni(a.norm[i]);
+        dist_prepare<KIND>(d, norm);
+#pragma unroll
+        for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
+        d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
+        d.inv_kappa_width = uni(d.inv_kappa_width);
+        d.neg_inverse_t = uni(d.neg_inverse_t);
+
+        if (g.lane == 0) {
+            s_qpark.hb = (a.heartbeat && (t | (1ull << 62)) == a.hb_task) ? a.heartbeat : nullptr;
+            if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
+        }
+        __syncthreads();
+
+        double val;
+        int st = 0;
+        if (!(norm == norm)) {
+            val = RIM_NAN;
+            st = ST_NORM_FAIL | ST_NONFINITE;
+        } else {
+            val = heyvaerts_coefficient<KIND>(pt, d, hc, g, inner, outer, &s_park, &s_qpark, st);
+        }
+        if (g.lane == 0) {
+            a.out[i * 8 + slot] = val;
+            if (a.status) a.status[i * 8 + slot] = st;
+            if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
+        }
+    }
+
+    __syncthreads();
+    if (g.lane == 0) {
+        atomicAdd(a.queue + 5, s_qpark.ctr.samples);
+        atomicAdd(a.queue + 6, s_qpark.ctr.steps);
+        atomicAdd(a.queue + 7, s_qpark.ctr.inner_qags);
+    }
+}
+
 // fills the slots that were not selected (or not yet available) with NaN
 __global__ void fill_unselected_kernel(double *out, int32_t *status, size_t n, uint32_t computed_mask)
 {
@@ -376,7 +452,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     memset(c, 0, sizeof *c);
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&c->d_queue, 4 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
+    if (hipMalloc(&c->d_queue, 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         (void) hipFree(c->d_queue);
         delete c;
@@ -474,6 +550,16 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     return RIMPHONY_OK;
 }
 
+template <int KIND>
+static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
+{
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
+    const unsigned grid = persistent_grid(c, ntasks, 16);
+    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
 extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n,
                                              const double *d_s, const double *d_theta,
                                              const double *const *d_params, uint32_t coeff_mask,
@@ -516,8 +602,13 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     for (int k = 0; k < 6; k++)     // symphony slots: j/alpha x I,Q,V
         if (coeff_mask & (1u << k)) { a.slot[a.nslots++] = k; computed |= 1u << k; }
     for (int k = a.nslots; k < 8; k++) a.slot[k] = 0;
+    SymArgs fa = a;                 // Faraday slots: rho_Q, rho_V
+    fa.nslots = 0;
+    for (int k = 6; k < 8; k++)
+        if (coeff_mask & (1u << k)) { fa.slot[fa.nslots++] = k; computed |= 1u << k; }
+    for (int k = fa.nslots; k < 8; k++) fa.slot[k] = 0;
 
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 8 * sizeof(unsigned long long), st));
     {
         const size_t total = n * 8;
         hipLaunchKernelGGL(fill_unselected_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
@@ -530,6 +621,15 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         case 1: rc = launch_symphony<1>(c, a, st); break;
         case 2: rc = launch_symphony<2>(c, a, st); break;
         default: rc = launch_symphony<3>(c, a, st); break;
+        }
+        if (rc) return rc;
+    }
+    if (fa.nslots > 0) {
+        switch (kind) {
+        case 0: rc = launch_heyvaerts<0>(c, fa, st); break;
+        case 1: rc = launch_heyvaerts<1>(c, fa, st); break;
+        case 2: rc = launch_heyvaerts<2>(c, fa, st); break;
+        default: rc = launch_heyvaerts<3>(c, fa, st); break;
         }
         if (rc) return rc;
     }
@@ -567,11 +667,14 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
 {
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[4];
+    unsigned long long h[8];
     HIP_TRY(hipMemcpy(h, c->d_queue, sizeof h, hipMemcpyDeviceToHost));
     out->samples = h[1];
     out->passes = h[2];
     out->inner_qags = h[3];
+    out->faraday_samples = h[5];
+    out->faraday_passes = h[6];
+    out->faraday_inner_qags = h[7];
     return RIMPHONY_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../rimphony_amd/csrc/symphony_wave.h"
+#include "../../rimphony_amd/csrc/heyvaerts_wave.h"
 
 using namespace rim;
 
@@ -11,6 +12,7 @@ using namespace rim;
 #define CAP_OUTER 128
 
 struct EmuTask {
+    int faraday;
     int kind, coeff, stokes;
     double s, theta, par[5], norm;
     double result[64];
@@ -41,7 +43,17 @@ static void lane_body(EmuTask *t)
     for (int k = 0; k < 5; k++) d.par[k] = t->par[k];
     dist_prepare<KIND>(d, t->norm);
     int st = 0;
-    const double val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
+    double val;
+    if (t->faraday) {
+        __shared__ HeyTask s_hpark;
+        HeyPoint hp;
+        hp.s = pt.s; hp.sin_th = pt.sin_th; hp.cos_th = pt.cos_th;
+        hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = t->stokes;
+        const HeyConsts hc = hey_consts();
+        val = heyvaerts_coefficient<KIND>(hp, d, hc, g, inner, outer, &s_hpark, &s_qpark, st);
+    } else {
+        val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
+    }
     t->result[g.lane] = val;
     t->status[g.lane] = st;
     wv_sync();
@@ -71,6 +83,7 @@ extern "C" int emu_symphony(int kind, int coeff, int stokes, double s, double th
                             double *result, int *status, unsigned long long *work3)
 {
     EmuTask t;
+    t.faraday = (coeff == 2);
     t.kind = kind; t.coeff = coeff; t.stokes = stokes; t.s = s; t.theta = theta; t.norm = norm;
     for (int k = 0; k < 5; k++) t.par[k] = par[k];
     pthread_barrier_init(&emu_wave().bar, nullptr, 64);

@@ -174,6 +174,32 @@ def test_symphony_other_distributions(gpu_ctx, oracle, cfg):
     _symphony_parity(gpu_ctx, oracle, cfg, 24, 0x3F)
 
 
+@pytest.mark.parametrize("cfg,n", [("cfg2_powerlaw_8", 64), ("cfg3_thermal_8", 48), ("cfg4_pitchypl_8", 48),
+                                   ("cfg5_pitchykappa_8", 48)])
+def test_faraday_bit_exact(gpu_ctx, oracle, cfg, n):
+    """Heyvaerts rho_Q / rho_V (slots 6, 7) against the oracle."""
+    _symphony_parity(gpu_ctx, oracle, cfg, n, 0xC0)
+
+
+def test_faraday_known_answers_on_gpu(gpu_ctx):
+    """The reference's four 1 % Faraday fixtures through the HIP path (power_law.rs:209-240,
+    thermal_juettner.rs:174-210)."""
+    from rimphony_amd import api
+    pl = api.PowerLawDistribution(2.5).gamma_limits(10., 1e12, 1e10).full_calculation(gpu_ctx)
+    assert abs(pl.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.Q, 1e4, 0.25 * math.pi) / 1.89e-9 - 1) < 0.01
+    assert abs(pl.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.V, 1e4, 0.25 * math.pi) / 5.28e-8 - 1) < 0.01
+    tj = api.ThermalJuettnerDistribution(10.).full_calculation(gpu_ctx)
+    assert abs(tj.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.Q, 4e4, 0.4) / 4.8081e-11 - 1) < 0.01
+    tj = api.ThermalJuettnerDistribution(0.1).full_calculation(gpu_ctx)
+    assert abs(tj.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.V, 40., 0.5) / 3.064e-4 - 1) < 0.01
+    assert math.isnan(pl.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.I, 1e4, 0.5))   # lib.rs:239-240
+
+
+def test_all_eight_slots_one_call(gpu_ctx, oracle):
+    """compute_all_dimensionless semantics: all 8 slots in the order of lib.rs:176-177."""
+    _symphony_parity(gpu_ctx, oracle, "cfg4_pitchypl_8", 12, 0xFF)
+
+
 def test_golden_file_subset_on_gpu(gpu_ctx):
     """The reference's own fixture (tests/symphony-powerlaw.txt, Symphony-C values, 1 %)
     evaluated through the HIP path: every 5th row, all six coefficients."""

@@ -1,0 +1,72 @@
+"""Pins the Heyvaerts (Faraday) part of the oracle: the four 1 % known answers the
+reference holds (power_law.rs:209-240, thermal_juettner.rs:174-210) and the
+series-based Bessel functions that stand in for the un-vendored special-fun crate."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import scipy.special as sp
+
+import oracle_bind
+
+CASES = [
+    # kind, params, s, theta, stokes, expected
+    (0, [2.5, 10., 1e12, 1e10], 1e4, 0.25 * math.pi, 1, 1.89e-9),     # pl_heyvaerts_high_freq_rho_q
+    (0, [2.5, 10., 1e12, 1e10], 1e4, 0.25 * math.pi, 2, 5.28e-8),     # pl_heyvaerts_high_freq_rho_v
+    (1, [10.], 4e4, 0.4, 1, 4.8081e-11),                               # tj_heyvaerts_high_freq_rho_q
+    (1, [0.1], 40., 0.5, 2, 3.064e-4),                                 # tj_heyvaerts_high_freq_rho_v
+]
+
+
+@pytest.mark.parametrize("flavour", ["det", "libm"])
+@pytest.mark.parametrize("case", CASES)
+def test_faraday_known_answers(flavour, case):
+    L = oracle_bind.load(flavour)
+    kind, par, s, th, stokes, expected = case
+    d, st = oracle_bind.mkdist(L, kind, par)
+    assert st == 0
+    v = L.rimo_compute_dimensionless(d, 2, stokes, s, th, None)
+    assert abs(v - expected) < 0.01 * expected, (v, expected)
+
+
+def _bind(L):
+    for n in ("rimo_bessel_i", "rimo_bessel_jnu", "rimo_bessel_ynu"):
+        getattr(L, n).restype = ctypes.c_double
+        getattr(L, n).argtypes = [ctypes.c_double, ctypes.c_double]
+    L.rimo_gamma_real.restype = ctypes.c_double
+    L.rimo_gamma_real.argtypes = [ctypes.c_double]
+    return L
+
+
+def test_series_bessel_functions_against_scipy(oracle):
+    L = _bind(oracle)
+    for nu in (1 / 3, -1 / 3, 2 / 3, -2 / 3):
+        for g in (1e-6, 0.01, 0.3, 1., 3., 9.99):      # the I branch is used for g < 10
+            assert abs(L.rimo_bessel_i(nu, g) / sp.iv(nu, g) - 1) < 2e-14
+    # the J/Y branch is only reachable for orders in (-1, 3) and small x (see rimo_heyvaerts.c)
+    for nu in (-0.9, -0.5, -0.2, 0.1, 0.5, 0.99, 1.3, 2.3, 2.7):
+        for x in (1e-5, 1e-3, 0.05, 0.25):
+            assert abs(L.rimo_bessel_jnu(nu, x) / sp.jv(nu, x) - 1) < 2e-14
+            assert abs(L.rimo_bessel_ynu(nu, x) / sp.yv(nu, x) - 1) < 1e-10   # reflection formula: cancellation near half-integers
+    # exactly integer order: documented 2^-26 step off the pole of the reflection formula
+    assert abs(L.rimo_bessel_ynu(2.0, 0.1) / sp.yv(2.0, 0.1) - 1) < 1e-6
+    for z in (1 / 3, 2 / 3, 4 / 3, 5 / 3, -0.5, -1.5, 2.5, 7.25):
+        assert abs(L.rimo_gamma_real(z) / sp.gamma(z) - 1) < 1e-14
+
+
+def test_faraday_via_dispatch(oracle):
+    d, _ = oracle_bind.mkdist(oracle, 0, [2.5, 10., 1e12, 1e10])
+    out = np.zeros(8)
+    oracle.rimo_compute_all_dimensionless.restype = None
+    oracle.rimo_compute_all_dimensionless.argtypes = [ctypes.POINTER(oracle_bind.Dist), ctypes.c_double, ctypes.c_double,
+                                                      ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+    oracle.rimo_compute_all_dimensionless(d, 1e4, 0.25 * math.pi, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), None)
+    assert np.isfinite(out).all()
+    assert abs(out[6] / 1.89e-9 - 1) < 0.01 and abs(out[7] / 5.28e-8 - 1) < 0.01
+    # pitchy_pl(k=0) == power_law for the Faraday coefficients too (pitchy_pl.rs:194-201)
+    d2, _ = oracle_bind.mkdist(oracle, 2, [2.5, 0., 10., 1e12, 1e10])
+    for stokes in (1, 2):
+        a = oracle.rimo_compute_dimensionless(d, 2, stokes, 1e2, 0.81, None)
+        b = oracle.rimo_compute_dimensionless(d2, 2, stokes, 1e2, 0.81, None)
+        assert abs(a / b - 1) < 1e-6
