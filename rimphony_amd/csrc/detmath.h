@@ -37,6 +37,23 @@
 RIM_FN uint64_t rim_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 RIM_FN double rim_frombits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 RIM_FN double rim_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+/* fma(a, b, K) for a compile-time constant K (Horner steps).  Same value as rim_fma.
+ * On gfx950 hipcc lowers fma-with-literal to a 2-address v_fmac_f64 preceded by two
+ * v_mov_b32 that copy the 64-bit literal into the destination (VOP3 cannot encode
+ * 64-bit literals): 3 VALU issues per Horner step.  Spelling the 3-address form keeps
+ * K in an SGPR pair (materialised by the scalar unit, which runs beside the VALU):
+ * 1 VALU issue per step. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rim_fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#else
+#define rim_fma_k(a, b, k) rim_fma(a, b, k)
+#endif
 RIM_FN double rim_sqrt(double x) { return __builtin_sqrt(x); }
 RIM_FN double rim_fabs(double x) { return __builtin_fabs(x); }
 RIM_FN double rim_floor(double x) { return __builtin_floor(x); }
@@ -67,17 +84,17 @@ RIM_FN double rim_exp_dd(double xh, double xl)
 
     /* exp(r) = 1 + r + r^2 * (1/2 + r/6 + ... + r^11/13!),  |r| <= 0.3466 */
     double q = 1.0 / 6227020800.0;              /* 1/13! */
-    q = rim_fma(q, r, 1.0 / 479001600.0);      /* 1/12! */
-    q = rim_fma(q, r, 1.0 / 39916800.0);
-    q = rim_fma(q, r, 1.0 / 3628800.0);
-    q = rim_fma(q, r, 1.0 / 362880.0);
-    q = rim_fma(q, r, 1.0 / 40320.0);
-    q = rim_fma(q, r, 1.0 / 5040.0);
-    q = rim_fma(q, r, 1.0 / 720.0);
-    q = rim_fma(q, r, 1.0 / 120.0);
-    q = rim_fma(q, r, 1.0 / 24.0);
-    q = rim_fma(q, r, 1.0 / 6.0);
-    q = rim_fma(q, r, 0.5);
+    q = rim_fma_k(q, r, 1.0 / 479001600.0);    /* 1/12! */
+    q = rim_fma_k(q, r, 1.0 / 39916800.0);
+    q = rim_fma_k(q, r, 1.0 / 3628800.0);
+    q = rim_fma_k(q, r, 1.0 / 362880.0);
+    q = rim_fma_k(q, r, 1.0 / 40320.0);
+    q = rim_fma_k(q, r, 1.0 / 5040.0);
+    q = rim_fma_k(q, r, 1.0 / 720.0);
+    q = rim_fma_k(q, r, 1.0 / 120.0);
+    q = rim_fma_k(q, r, 1.0 / 24.0);
+    q = rim_fma_k(q, r, 1.0 / 6.0);
+    q = rim_fma_k(q, r, 0.5);
     const double t = rim_fma(q * r, r, r);     /* r + r^2 q */
     const double p = 1.0 + t;
     return rim_ldexp(p, k);
@@ -122,16 +139,16 @@ RIM_FN double rim_log_dd(double x, double *lo)
     /* atanh(s)/s - 1 = z/3 + z^2/5 + ... + z^11/23,  z = s^2 <= 0.0295 */
     const double z = sh * sh;
     double q = 1.0 / 23.0;
-    q = rim_fma(q, z, 1.0 / 21.0);
-    q = rim_fma(q, z, 1.0 / 19.0);
-    q = rim_fma(q, z, 1.0 / 17.0);
-    q = rim_fma(q, z, 1.0 / 15.0);
-    q = rim_fma(q, z, 1.0 / 13.0);
-    q = rim_fma(q, z, 1.0 / 11.0);
-    q = rim_fma(q, z, 1.0 / 9.0);
-    q = rim_fma(q, z, 1.0 / 7.0);
-    q = rim_fma(q, z, 1.0 / 5.0);
-    q = rim_fma(q, z, 1.0 / 3.0);
+    q = rim_fma_k(q, z, 1.0 / 21.0);
+    q = rim_fma_k(q, z, 1.0 / 19.0);
+    q = rim_fma_k(q, z, 1.0 / 17.0);
+    q = rim_fma_k(q, z, 1.0 / 15.0);
+    q = rim_fma_k(q, z, 1.0 / 13.0);
+    q = rim_fma_k(q, z, 1.0 / 11.0);
+    q = rim_fma_k(q, z, 1.0 / 9.0);
+    q = rim_fma_k(q, z, 1.0 / 7.0);
+    q = rim_fma_k(q, z, 1.0 / 5.0);
+    q = rim_fma_k(q, z, 1.0 / 3.0);
     q = q * z;
 
     /* log m = 2 sh + (2 sl + 2 sh q) */
@@ -227,12 +244,12 @@ RIM_FN double rim_lgamma_stirling(double x)
     const double w = 1.0 / x;
     const double w2 = w * w;
     double t = 1.0 / 156.0;
-    t = rim_fma(t, w2, -691.0 / 360360.0);
-    t = rim_fma(t, w2, 1.0 / 1188.0);
-    t = rim_fma(t, w2, -1.0 / 1680.0);
-    t = rim_fma(t, w2, 1.0 / 1260.0);
-    t = rim_fma(t, w2, -1.0 / 360.0);
-    t = rim_fma(t, w2, 1.0 / 12.0);
+    t = rim_fma_k(t, w2, -691.0 / 360360.0);
+    t = rim_fma_k(t, w2, 1.0 / 1188.0);
+    t = rim_fma_k(t, w2, -1.0 / 1680.0);
+    t = rim_fma_k(t, w2, 1.0 / 1260.0);
+    t = rim_fma_k(t, w2, -1.0 / 360.0);
+    t = rim_fma_k(t, w2, 1.0 / 12.0);
     t = t * w;
     /* ph - x + (pl + t + 0.5 log(2 pi)) */
     const double HALF_LOG_2PI = 9.18938533204672741780e-01;
@@ -281,20 +298,20 @@ RIM_FN void rim_sincos(double x, double *sn, double *cs)
     double s = 1.0 / 121645100408832000.0;           /* 1/19! */
     s = rim_fma(s, z, -1.0 / 355687428096000.0);     /* 1/17! */
     s = rim_fma(s, z, 1.0 / 1307674368000.0);        /* 1/15! */
-    s = rim_fma(s, z, -1.0 / 6227020800.0);
-    s = rim_fma(s, z, 1.0 / 39916800.0);
-    s = rim_fma(s, z, -1.0 / 362880.0);
-    s = rim_fma(s, z, 1.0 / 5040.0);
-    s = rim_fma(s, z, -1.0 / 120.0);
+    s = rim_fma_k(s, z, -1.0 / 6227020800.0);
+    s = rim_fma_k(s, z, 1.0 / 39916800.0);
+    s = rim_fma_k(s, z, -1.0 / 362880.0);
+    s = rim_fma_k(s, z, 1.0 / 5040.0);
+    s = rim_fma_k(s, z, -1.0 / 120.0);
     s = rim_fma(s, z, 1.0 / 6.0);                    /* note sign folded below */
     double c = -1.0 / 6402373705728000.0;            /* -1/18! */
     c = rim_fma(c, z, 1.0 / 20922789888000.0);       /* 1/16! */
-    c = rim_fma(c, z, -1.0 / 87178291200.0);
-    c = rim_fma(c, z, 1.0 / 479001600.0);
-    c = rim_fma(c, z, -1.0 / 3628800.0);
-    c = rim_fma(c, z, 1.0 / 40320.0);
-    c = rim_fma(c, z, -1.0 / 720.0);
-    c = rim_fma(c, z, 1.0 / 24.0);
+    c = rim_fma_k(c, z, -1.0 / 87178291200.0);
+    c = rim_fma_k(c, z, 1.0 / 479001600.0);
+    c = rim_fma_k(c, z, -1.0 / 3628800.0);
+    c = rim_fma_k(c, z, 1.0 / 40320.0);
+    c = rim_fma_k(c, z, -1.0 / 720.0);
+    c = rim_fma_k(c, z, 1.0 / 24.0);
     /* sin r = rh - rh z s' with s' = 1/6 - z/120 + ... ; above built with
      * alternating signs so that s = 1/6 - z/120 + z^2/5040 - ... */
     const double sin_r = rim_fma(-(rh * z), s, rh);

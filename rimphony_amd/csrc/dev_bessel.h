@@ -46,12 +46,12 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
     if (a < 1e-3) {
         const double x = f_exp;
         double q = 8 + x;
-        q = rim_fma(q, x, 56.);
-        q = rim_fma(q, x, 336.);
-        q = rim_fma(q, x, 1680.);
-        q = rim_fma(q, x, 6720.);
-        q = rim_fma(q, x, 20160.);
-        q = rim_fma(q, x, 40320.);
+        q = rim_fma_k(q, x, 56.);
+        q = rim_fma_k(q, x, 336.);
+        q = rim_fma_k(q, x, 1680.);
+        q = rim_fma_k(q, x, 6720.);
+        q = rim_fma_k(q, x, 20160.);
+        q = rim_fma_k(q, x, 40320.);
         return f_factor * (1 + (q * x / 40320.));
     }
     if (a > 690.) {
@@ -107,42 +107,42 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     const double t = z * z;
 
     double a7, a6, a5, a4, a3, a2, a1, a0;
-    a7 = rim_fma(59968440., t, 4450158720.);
-    a7 = rim_fma(a7, t, 38435160960.);
-    a7 = rim_fma(a7, t, 86387857920.);
-    a7 = rim_fma(a7, t, 60631119360.);
-    a7 = rim_fma(a7, t, 12841758720.);
-    a7 = rim_fma(a7, t, 625766400.);
-    a7 = rim_fma(a7, t, 2580480.);
-    a7 = rim_fma(a7, t, 0.);
-    a6 = rim_fma(-16907985., t, -954875250.);
-    a6 = rim_fma(a6, t, -5897669400.);
-    a6 = rim_fma(a6, t, -8653594320.);
-    a6 = rim_fma(a6, t, -3405435264.);
-    a6 = rim_fma(a6, t, -299351808.);
-    a6 = rim_fma(a6, t, -2644992.);
-    a6 = rim_fma(a6, t, 6144.);
-    a5 = rim_fma(5537280., t, 228049920.);
-    a5 = rim_fma(a5, t, 940423680.);
-    a5 = rim_fma(a5, t, 800163840.);
-    a5 = rim_fma(a5, t, 138700800.);
-    a5 = rim_fma(a5, t, 2580480.);
-    a5 = rim_fma(a5, t, 0.);
-    a4 = rim_fma(-2163168., t, -61254720.);
-    a4 = rim_fma(a4, t, -151828480.);
-    a4 = rim_fma(a4, t, -60518400.);
-    a4 = rim_fma(a4, t, -2519040.);
-    a4 = rim_fma(a4, t, -8192.);
-    a3 = rim_fma(-1048320., t, -18708480.);
-    a3 = rim_fma(a3, t, -23224320.);
-    a3 = rim_fma(a3, t, -2580480.);
-    a3 = rim_fma(a3, t, 0.);
-    a2 = rim_fma(672000., t, 6547968.);
-    a2 = rim_fma(a2, t, 2709504.);
-    a2 = rim_fma(a2, t, -28672.);
-    a1 = rim_fma(-645120., t, -2580480.);
-    a1 = rim_fma(a1, t, 0.);
-    a0 = rim_fma(1290240., t, 860160.);
+    a7 = rim_fma_k(59968440., t, 4450158720.);
+    a7 = rim_fma_k(a7, t, 38435160960.);
+    a7 = rim_fma_k(a7, t, 86387857920.);
+    a7 = rim_fma_k(a7, t, 60631119360.);
+    a7 = rim_fma_k(a7, t, 12841758720.);
+    a7 = rim_fma_k(a7, t, 625766400.);
+    a7 = rim_fma_k(a7, t, 2580480.);
+    a7 = rim_fma_k(a7, t, 0.);
+    a6 = rim_fma_k(-16907985., t, -954875250.);
+    a6 = rim_fma_k(a6, t, -5897669400.);
+    a6 = rim_fma_k(a6, t, -8653594320.);
+    a6 = rim_fma_k(a6, t, -3405435264.);
+    a6 = rim_fma_k(a6, t, -299351808.);
+    a6 = rim_fma_k(a6, t, -2644992.);
+    a6 = rim_fma_k(a6, t, 6144.);
+    a5 = rim_fma_k(5537280., t, 228049920.);
+    a5 = rim_fma_k(a5, t, 940423680.);
+    a5 = rim_fma_k(a5, t, 800163840.);
+    a5 = rim_fma_k(a5, t, 138700800.);
+    a5 = rim_fma_k(a5, t, 2580480.);
+    a5 = rim_fma_k(a5, t, 0.);
+    a4 = rim_fma_k(-2163168., t, -61254720.);
+    a4 = rim_fma_k(a4, t, -151828480.);
+    a4 = rim_fma_k(a4, t, -60518400.);
+    a4 = rim_fma_k(a4, t, -2519040.);
+    a4 = rim_fma_k(a4, t, -8192.);
+    a3 = rim_fma_k(-1048320., t, -18708480.);
+    a3 = rim_fma_k(a3, t, -23224320.);
+    a3 = rim_fma_k(a3, t, -2580480.);
+    a3 = rim_fma_k(a3, t, 0.);
+    a2 = rim_fma_k(672000., t, 6547968.);
+    a2 = rim_fma_k(a2, t, 2709504.);
+    a2 = rim_fma_k(a2, t, -28672.);
+    a1 = rim_fma_k(-645120., t, -2580480.);
+    a1 = rim_fma_k(a1, t, 0.);
+    a0 = rim_fma_k(1290240., t, 860160.);
 
     double v = a7;
     v = rim_fma(v, U, a6);
@@ -158,24 +158,24 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
 
     double exp_val;
     if (eps < 1e-4 && o.big_n) {
-        double q = rim_fma(0.139204065e9, eps, 0.160692840e9);
-        q = rim_fma(q, eps, 0.190139040e9);
-        q = rim_fma(q, eps, 0.233192960e9);
-        q = rim_fma(q, eps, 0.303114240e9);
-        q = rim_fma(q, eps, 0.442810368e9);
-        q = rim_fma(q, eps, 0.984023040e9);
+        double q = rim_fma_k(0.139204065e9, eps, 0.160692840e9);
+        q = rim_fma_k(q, eps, 0.190139040e9);
+        q = rim_fma_k(q, eps, 0.233192960e9);
+        q = rim_fma_k(q, eps, 0.303114240e9);
+        q = rim_fma_k(q, eps, 0.442810368e9);
+        q = rim_fma_k(q, eps, 0.984023040e9);
         const double exp2 = -n * rim_sqrt(2. * eps) * eps * q / 0.1476034560e10;
         exp_val = o.small_eps_const + exp2 - vsum1 - o.vsum2;
     } else {
         double invZp1;
         if (Z < 1.e-3) {
             double q = 1 - Z;
-            q = rim_fma(q, Z, -1.);
-            q = rim_fma(q, Z, 1.);
-            q = rim_fma(q, Z, -1.);
-            q = rim_fma(q, Z, 1.);
-            q = rim_fma(q, Z, -1.);
-            q = rim_fma(q, Z, 1.);
+            q = rim_fma_k(q, Z, -1.);
+            q = rim_fma_k(q, Z, 1.);
+            q = rim_fma_k(q, Z, -1.);
+            q = rim_fma_k(q, Z, 1.);
+            q = rim_fma_k(q, Z, -1.);
+            q = rim_fma_k(q, Z, 1.);
             invZp1 = q;
         } else {
             invZp1 = 1. / (1. + Z);
@@ -200,50 +200,50 @@ RIM_DEV double debye_eps(double n, double x)
 
     double q, p;
     // innermost first: d13, then d12 .. d0 folded into the running Horner value
-    p = rim_fma(14875. * RIM_AT15, ez * ez, rim_fma(3123750. * RIM_AT13, t3, -833000. * RIM_AT15));
+    p = rim_fma(14875. * RIM_AT15, ez * ez, rim_fma_k(3123750. * RIM_AT13, t3, -833000. * RIM_AT15));
     p = rim_fma(p, ez, (40608750. * RIM_AT12) * x);                                       // d12
-    p = rim_fma(p, ez, rim_fma(-113704500. * RIM_AT13, t3, 17481100. * RIM_AT15));        // d11
-    q = rim_fma(5360355000. * RIM_AT10, t3, -1161410250. * RIM_AT12);
+    p = rim_fma(p, ez, rim_fma_k(-113704500. * RIM_AT13, t3, 17481100. * RIM_AT15));        // d11
+    q = rim_fma_k(5360355000. * RIM_AT10, t3, -1161410250. * RIM_AT12);
     p = rim_fma(p, ez, q * x);                                                            // d10
     q = 53603550000. * RIM_AT9;
-    q = rim_fma(q, t4, 1474097625. * RIM_AT13);
-    p = rim_fma(p, ez, rim_fma(q, t3, -173573400. * RIM_AT15));                           // d9
-    q = rim_fma(-88445857500. * RIM_AT10, t3, 11448186750. * RIM_AT12);
+    q = rim_fma_k(q, t4, 1474097625. * RIM_AT13);
+    p = rim_fma(p, ez, rim_fma_k(q, t3, -173573400. * RIM_AT15));                           // d9
+    q = rim_fma_k(-88445857500. * RIM_AT10, t3, 11448186750. * RIM_AT12);
     p = rim_fma(p, ez, q * x);                                                            // d8
-    q = rim_fma(3859455600000. * RIM_AT7, t3, -643242600000. * RIM_AT9);
-    q = rim_fma(q, t4, -8397889500. * RIM_AT13);
-    p = rim_fma(p, ez, rim_fma(q, t3, 849093050. * RIM_AT15));                            // d7
+    q = rim_fma_k(3859455600000. * RIM_AT7, t3, -643242600000. * RIM_AT9);
+    q = rim_fma_k(q, t4, -8397889500. * RIM_AT13);
+    p = rim_fma(p, ez, rim_fma_k(q, t3, 849093050. * RIM_AT15));                            // d7
     q = 27016189200000. * RIM_AT6;
-    q = rim_fma(q, t4, 459918459000. * RIM_AT10);
-    q = rim_fma(q, t3, -47153256150. * RIM_AT12);
+    q = rim_fma_k(q, t4, 459918459000. * RIM_AT10);
+    q = rim_fma_k(q, t3, -47153256150. * RIM_AT12);
     p = rim_fma(p, ez, q * x);                                                            // d6
-    q = rim_fma(-21612951360000. * RIM_AT7, t3, 2283511230000. * RIM_AT9);
-    q = rim_fma(q, t4, 20997160275. * RIM_AT13);
-    p = rim_fma(p, ez, rim_fma(q, t3, -1938419560. * RIM_AT15));                          // d5
-    q = rim_fma(K38, t3, -94556662200000. * RIM_AT6);
-    q = rim_fma(q, t4, -860873013000. * RIM_AT10);
-    q = rim_fma(q, t3, 78248884350. * RIM_AT12);
+    q = rim_fma_k(-21612951360000. * RIM_AT7, t3, 2283511230000. * RIM_AT9);
+    q = rim_fma_k(q, t4, 20997160275. * RIM_AT13);
+    p = rim_fma(p, ez, rim_fma_k(q, t3, -1938419560. * RIM_AT15));                          // d5
+    q = rim_fma_k(K38, t3, -94556662200000. * RIM_AT6);
+    q = rim_fma_k(q, t4, -860873013000. * RIM_AT10);
+    q = rim_fma_k(q, t3, 78248884350. * RIM_AT12);
     p = rim_fma(p, ez, q * x);                                                            // d4
     q = 3241942704000000. * RIM_AT3;
-    q = rim_fma(q, t4, 29331862560000. * RIM_AT7);
-    q = rim_fma(q, t3, -2594411820000. * RIM_AT9);
-    q = rim_fma(q, t4, -19964735910. * RIM_AT13);
-    p = rim_fma(p, ez, rim_fma(q, t3, 1748257220. * RIM_AT15));                           // d3
-    q = rim_fma(-K38, t3, 67540473000000. * RIM_AT6);
-    q = rim_fma(q, t4, 484040056500. * RIM_AT10);
-    q = rim_fma(q, t3, -41423013450. * RIM_AT12);
+    q = rim_fma_k(q, t4, 29331862560000. * RIM_AT7);
+    q = rim_fma_k(q, t3, -2594411820000. * RIM_AT9);
+    q = rim_fma_k(q, t4, -19964735910. * RIM_AT13);
+    p = rim_fma(p, ez, rim_fma_k(q, t3, 1748257220. * RIM_AT15));                           // d3
+    q = rim_fma_k(-K38, t3, 67540473000000. * RIM_AT6);
+    q = rim_fma_k(q, t4, 484040056500. * RIM_AT10);
+    q = rim_fma_k(q, t3, -41423013450. * RIM_AT12);
     p = rim_fma(p, ez, q * x);                                                            // d2
     q = 19451656224000000. * RIM_AT1;
-    q = rim_fma(q, t3, -1296777081600000. * RIM_AT3);
-    q = rim_fma(q, t4, -8027667648000. * RIM_AT7);
-    q = rim_fma(q, t3, 8027667648000. * RIM_AT9);
-    q = rim_fma(q, z, -36011689560. * RIM_AT10);
-    q = rim_fma(q, t3, 3012121710. * RIM_AT12);
-    q = rim_fma(q, z, 4707059994. * RIM_AT13);
-    p = rim_fma(p, ez, rim_fma(q, t3, -401283384. * RIM_AT15));                           // d1
+    q = rim_fma_k(q, t3, -1296777081600000. * RIM_AT3);
+    q = rim_fma_k(q, t4, -8027667648000. * RIM_AT7);
+    q = rim_fma_k(q, t3, 8027667648000. * RIM_AT9);
+    q = rim_fma_k(q, z, -36011689560. * RIM_AT10);
+    q = rim_fma_k(q, t3, 3012121710. * RIM_AT12);
+    q = rim_fma_k(q, z, 4707059994. * RIM_AT13);
+    p = rim_fma(p, ez, rim_fma_k(q, t3, -401283384. * RIM_AT15));                           // d1
     q = 19451656224000000. * RIM_AT0;
-    q = rim_fma(q, t4, 69470200800000. * RIM_AT4);
-    q = rim_fma(q, t3, -5403237840000. * RIM_AT6);
+    q = rim_fma_k(q, t4, 69470200800000. * RIM_AT4);
+    q = rim_fma_k(q, t3, -5403237840000. * RIM_AT6);
     p = rim_fma(p, ez, q * t10 * z);                                                      // d0
 
     return p / (RIM_PI * t146 * 0.58354968672000000e17);
