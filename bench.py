@@ -30,18 +30,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# DESIGN.md "Algorithmic work per unit": fp64 flops per integrand sample
-# (power-law distribution; FMA = 2, add/mul/div/sqrt = 1), counted from the source.
-FLOPS_PER_SAMPLE = 800.0
+# DESIGN.md "Algorithmic work per unit": fp64 flops per integrand sample (power-law
+# distribution; FMA = 2, add/mul/div/sqrt = 1, elementary functions expanded), counted from
+# the source and weighted by the measured Bessel-region mix of this table
+# (Debye 21 %, Meissel-1 73 %, blend 5 %, integer order 1 %).
+FLOPS_PER_SAMPLE = 720.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=32768, help="table rows per GPU per step")
+    ap.add_argument("--points", type=int, default=65536, help="table rows per GPU per step")
     ap.add_argument("--config", default="cfg2_powerlaw_jI_aI")
     ap.add_argument("--cpu-sample", type=int, default=512, help="points of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()

@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librimphony_hip.so")
+LIB_PATH = os.environ.get("RIMPHONY_HIP_LIB") or os.path.join(_HERE, "librimphony_hip.so")   # env override: tuning builds
 
 SYMBOLS = [
     "rimphony_dist_nparams", "rimphony_ctx_create", "rimphony_ctx_destroy", "rimphony_strerror",

@@ -21,9 +21,21 @@
 
 using namespace rim;
 
-#define CAP_INNER 128
-#define CAP_OUTER 128
+// LDS subinterval-store capacities.  Largest counts seen on the reference's golden file and
+// on the bench tables: 31 (gamma integrals), 41 (n chunks), 48 (normalisation).
+#ifndef CAP_INNER
+#define CAP_INNER 64
+#endif
+#ifndef CAP_OUTER
+#define CAP_OUTER 64
+#endif
 #define CAP_NORM 256
+// minimum waves per SIMD the register allocator must leave room for (symphony kernel)
+// (measured on MI355X, 65536-point launches: 4 -> 25.8k, 5 -> 27.0k, 6 -> 27.8k points/s; at 6 the
+// allocator spills 47 VGPRs to scratch and still wins)
+#ifndef RIM_SYM_WAVES
+#define RIM_SYM_WAVES 6
+#endif
 
 // ------------------------------------------------------------------------------
 // normalisation integrands (power_law.rs:95-96, pitchy_kappa.rs:100-104; the
@@ -135,6 +147,7 @@ struct SymArgs {
     int nslots;
     int slot[8];
     unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
+    const unsigned *perm;           // task order (expensive points first) or null
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
 };
@@ -143,7 +156,7 @@ __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
 __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 
 template <int KIND>
-__global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
+__global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 {
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
@@ -160,7 +173,8 @@ __global__ __launch_bounds__(64) void symphony_kernel(SymArgs a)
         const unsigned long long t = wave_next_task(a.queue, g.lane);
         if (t >= ntasks) break;
         // slot-major within a point: consecutive tasks share the point's inputs in L2
-        const size_t i = (size_t) (t / (unsigned) a.nslots);
+        const size_t seq = (size_t) (t / (unsigned) a.nslots);
+        const size_t i = a.perm ? (size_t) a.perm[seq] : seq;
         const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
 
         SymPoint pt;
@@ -235,7 +249,8 @@ __global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
     for (;;) {
         const unsigned long long t = wave_next_task(a.queue + 4, g.lane);
         if (t >= ntasks) break;
-        const size_t i = (size_t) (t / (unsigned) a.nslots);
+        const size_t seq = (size_t) (t / (unsigned) a.nslots);
+        const size_t i = a.perm ? (size_t) a.perm[seq] : seq;
         const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
 
         HeyPoint pt;
@@ -284,6 +299,41 @@ __global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
         atomicAdd(a.queue + 6, s_qpark.ctr.steps);
         atomicAdd(a.queue + 7, s_qpark.ctr.inner_qags);
     }
+}
+
+// ------------------------------------------------------------------------------
+// expensive-first task order.  The cost of a point grows with s (about 3x from s < 10 to
+// s > 100 on the bench tables), so points are bucketed by the binary exponent of s and the
+// persistent grid starts with the large-s buckets: the cheap points then fill the tail of the
+// launch.  Only the order of evaluation changes, never a result.
+// ------------------------------------------------------------------------------
+#define ORDER_BUCKETS 32
+
+__device__ __forceinline__ int order_bucket(double s)
+{
+    const int e = (int) ((rim_bits(s) >> 52) & 0x7ff) - 1023;     // floor(log2 s) for normal s
+    int b = 16 - e;                                                 // large s -> small bucket index
+    return b < 0 ? 0 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
+}
+
+__global__ void order_hist_kernel(const double *s, size_t n, unsigned *hist)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[order_bucket(s[i])], 1u);
+}
+
+__global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, one thread
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned acc = 0;
+        for (int b = 0; b < ORDER_BUCKETS; b++) { const unsigned c = hist[b]; hist[b] = acc; acc += c; }
+    }
+}
+
+__global__ void order_scatter_kernel(const double *s, size_t n, unsigned *offsets, unsigned *perm)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i])], 1u)] = (unsigned) i;
 }
 
 // fills the slots that were not selected (or not yet available) with NaN
@@ -390,6 +440,7 @@ struct rimphony_ctx {
     int n_cu;
     unsigned long long *d_queue;   // 4 words
     double *d_norm;
+    unsigned *d_perm;               // [norm_cap] task order + ORDER_BUCKETS histogram words behind it
     size_t norm_cap;
     // staging for the host-buffer entry point
     double *d_in;
@@ -468,6 +519,7 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     (void) hipSetDevice(c->device);
     if (c->d_queue) (void) hipFree(c->d_queue);
     if (c->d_norm) (void) hipFree(c->d_norm);
+    if (c->d_perm) (void) hipFree(c->d_perm);
     if (c->d_in) (void) hipFree(c->d_in);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_status) (void) hipFree(c->d_status);
@@ -481,9 +533,12 @@ static int ensure_norm(rimphony_ctx *c, size_t n)
 {
     if (c->norm_cap >= n) return RIMPHONY_OK;
     if (c->d_norm) (void) hipFree(c->d_norm);
+    if (c->d_perm) (void) hipFree(c->d_perm);
     c->d_norm = nullptr;
+    c->d_perm = nullptr;
     c->norm_cap = 0;
     if (hipMalloc(&c->d_norm, n * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+    if (hipMalloc(&c->d_perm, (n + ORDER_BUCKETS) * sizeof(unsigned)) != hipSuccess) return RIMPHONY_ENOMEM;
     c->norm_cap = n;
     return RIMPHONY_OK;
 }
@@ -541,7 +596,7 @@ template <int KIND>
 static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
-    const unsigned grid = persistent_grid(c, ntasks, 16);
+    const unsigned grid = persistent_grid(c, ntasks, 4 * RIM_SYM_WAVES);
     HIP_TRY(hipEventRecord(c->ev_start, st));
     hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
@@ -595,6 +650,17 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     a.status = d_status;
     a.n = n;
     a.queue = c->d_queue;
+    a.perm = nullptr;
+    if (n > 4096 && n < 0xffffffffull) {
+        unsigned *hist = c->d_perm + c->norm_cap;
+        const unsigned nb = (unsigned) ((n + 255) / 256);
+        HIP_TRY(hipMemsetAsync(hist, 0, ORDER_BUCKETS * sizeof(unsigned), st));
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, d_s, n, hist);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, st, hist);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, d_s, n, hist, c->d_perm);
+        HIP_TRY(hipGetLastError());
+        a.perm = c->d_perm;
+    }
     a.heartbeat = c->hb_dev;
     a.hb_task = c->hb_task;
     a.nslots = 0;
