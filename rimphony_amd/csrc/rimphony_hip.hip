@@ -30,6 +30,11 @@ using namespace rim;
 #define CAP_OUTER 64
 #endif
 #define CAP_NORM 256
+// per-wave global spill behind the LDS stores: the GSL limits of the path (5000 inner for
+// Symphony, 4096 for Heyvaerts, 1000 / 4096 outer)
+#define SPILL_INNER 5000
+#define SPILL_OUTER 4096
+#define SPILL_DOUBLES_PER_WAVE (RIM_ISTORE_DOUBLES(SPILL_INNER) + RIM_ISTORE_DOUBLES(SPILL_OUTER))
 // minimum waves per SIMD the register allocator must leave room for (symphony kernel)
 // (measured on MI355X, 65536-point launches: 4 -> 25.8k, 5 -> 27.0k, 6 -> 27.8k points/s; at 6 the
 // allocator spills 47 VGPRs to scratch and still wins)
@@ -96,12 +101,13 @@ __device__ __forceinline__ unsigned long long wave_next_task(unsigned long long 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double *norm, unsigned long long *queue)
+__global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double *norm, unsigned long long *queue,
+                                                    double *spill_base)
 {
     __shared__ double s_tab[96];
     __shared__ double s_store[RIM_ISTORE_DOUBLES(CAP_NORM)];
     const GKLane g = gk_lane_init(s_tab);
-    const IStore st = istore_carve(s_store, CAP_NORM);
+    const IStore st = istore_carve(s_store, CAP_NORM, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
@@ -148,6 +154,7 @@ struct SymArgs {
     int slot[8];
     unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
     const unsigned *perm;           // task order (expensive points first) or null
+    double *spill;                  // [gridDim.x][SPILL_DOUBLES_PER_WAVE] wave-private global store overflow
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
 };
@@ -163,8 +170,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
     __shared__ TaskState s_park;
     const GKLane g = gk_lane_init(s_tab);
-    const IStore inner = istore_carve(s_inner, CAP_INNER);
-    const IStore outer = istore_carve(s_outer, CAP_OUTER);
+    double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
@@ -237,8 +245,9 @@ __global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
     __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
     __shared__ HeyTask s_park;
     const GKLane g = gk_lane_init(s_tab);
-    const IStore inner = istore_carve(s_inner, CAP_INNER);
-    const IStore outer = istore_carve(s_outer, CAP_OUTER);
+    double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
@@ -368,12 +377,12 @@ struct PointArgs {
 
 template <int KIND>
 __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const double *norm_ptr, size_t count,
-                                                            const double *nvals, double *out)
+                                                            const double *nvals, double *out, double *spill_base)
 {
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
     const GKLane g = gk_lane_init(s_tab);
-    const IStore inner = istore_carve(s_inner, CAP_INNER);
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
     SymPoint pt;
@@ -408,12 +417,13 @@ __device__ inline double selftest_integrand(int family, double p0, double p1, do
 __global__ __launch_bounds__(64) void qag_selftest_kernel(size_t count, const int32_t *family, const double *p0,
                                                           const double *p1, const double *a, const double *b,
                                                           double epsabs, double epsrel, int limit,
-                                                          double *result, double *abserr, int32_t *qstatus, int32_t *size)
+                                                          double *result, double *abserr, int32_t *qstatus, int32_t *size,
+                                                          double *spill_base)
 {
     __shared__ double s_tab[96];
     __shared__ double s_store[RIM_ISTORE_DOUBLES(CAP_NORM)];
     const GKLane g = gk_lane_init(s_tab);
-    const IStore st = istore_carve(s_store, CAP_NORM);
+    const IStore st = istore_carve(s_store, CAP_NORM, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
     for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
@@ -441,6 +451,8 @@ struct rimphony_ctx {
     unsigned long long *d_queue;   // 4 words
     double *d_norm;
     unsigned *d_perm;               // [norm_cap] task order + ORDER_BUCKETS histogram words behind it
+    double *d_spill;                // [spill_waves][SPILL_DOUBLES_PER_WAVE]
+    size_t spill_waves;
     size_t norm_cap;
     // staging for the host-buffer entry point
     double *d_in;
@@ -520,6 +532,7 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     if (c->d_queue) (void) hipFree(c->d_queue);
     if (c->d_norm) (void) hipFree(c->d_norm);
     if (c->d_perm) (void) hipFree(c->d_perm);
+    if (c->d_spill) (void) hipFree(c->d_spill);
     if (c->d_in) (void) hipFree(c->d_in);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_status) (void) hipFree(c->d_status);
@@ -527,6 +540,17 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
     delete c;
+}
+
+static int ensure_spill(rimphony_ctx *c, size_t waves)
+{
+    if (c->spill_waves >= waves) return RIMPHONY_OK;
+    if (c->d_spill) (void) hipFree(c->d_spill);
+    c->d_spill = nullptr;
+    c->spill_waves = 0;
+    if (hipMalloc(&c->d_spill, waves * SPILL_DOUBLES_PER_WAVE * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+    c->spill_waves = waves;
+    return RIMPHONY_OK;
 }
 
 static int ensure_norm(rimphony_ctx *c, size_t n)
@@ -557,7 +581,9 @@ static int launch_norm(rimphony_ctx *c, size_t n, const ParamPtrs &pp, double *d
 {
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), st));
     const unsigned grid = persistent_grid(c, n, 16);
-    hipLaunchKernelGGL(norm_kernel<KIND>, dim3(grid), dim3(64), 0, st, pp, n, d_norm, c->d_queue);
+    int rc = ensure_spill(c, grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(norm_kernel<KIND>, dim3(grid), dim3(64), 0, st, pp, n, d_norm, c->d_queue, c->d_spill);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }
@@ -597,8 +623,12 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
     const unsigned grid = persistent_grid(c, ntasks, 4 * RIM_SYM_WAVES);
+    int rc = ensure_spill(c, grid);
+    if (rc) return rc;
+    SymArgs b = a;
+    b.spill = c->d_spill;
     HIP_TRY(hipEventRecord(c->ev_start, st));
-    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, st));
     c->ev_valid = 1;
@@ -610,7 +640,11 @@ static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
     const unsigned grid = persistent_grid(c, ntasks, 16);
-    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), 0, st, a);
+    int rc = ensure_spill(c, grid);
+    if (rc) return rc;
+    SymArgs b = a;
+    b.spill = c->d_spill;
+    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }
@@ -651,6 +685,7 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     a.n = n;
     a.queue = c->d_queue;
     a.perm = nullptr;
+    a.spill = nullptr;
     if (n > 4096 && n < 0xffffffffull) {
         unsigned *hist = c->d_perm + c->norm_cap;
         const unsigned nb = (unsigned) ((n + 255) / 256);
@@ -883,11 +918,13 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     rc = single_point_norm(c, kind, params, st);
     if (rc) return rc;
     const unsigned grid = persistent_grid(c, count, 16);
+    rc = ensure_spill(c, grid);
+    if (rc) return rc;
     switch (kind) {
-    case 0: hipLaunchKernelGGL(gamma_integral_kernel<0>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
-    case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
-    case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
-    default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out); break;
+    case 0: hipLaunchKernelGGL(gamma_integral_kernel<0>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
@@ -905,8 +942,10 @@ extern "C" int rimphony_qag_selftest_device(rimphony_ctx *c, size_t count, const
     if (count == 0) return RIMPHONY_OK;
     HIP_TRY(hipSetDevice(c->device));
     const unsigned grid = persistent_grid(c, count, 16);
+    int rc = ensure_spill(c, grid);
+    if (rc) return rc;
     hipLaunchKernelGGL(qag_selftest_kernel, dim3(grid), dim3(64), 0, (hipStream_t) stream, count, d_family, d_p0, d_p1,
-                       d_a, d_b, epsabs, epsrel, (int) limit, d_result, d_abserr, d_qstatus, d_size);
+                       d_a, d_b, epsabs, epsrel, (int) limit, d_result, d_abserr, d_qstatus, d_size, c->d_spill);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }

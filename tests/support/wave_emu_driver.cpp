@@ -8,8 +8,8 @@
 
 using namespace rim;
 
-#define CAP_INNER 128
-#define CAP_OUTER 128
+#define CAP_INNER 64
+#define CAP_OUTER 64
 
 struct EmuTask {
     int faraday;
@@ -29,8 +29,9 @@ static void lane_body(EmuTask *t)
     __shared__ TaskState s_park;
     __shared__ QagPark s_qpark;
     const GKLane g = gk_lane_init(s_tab);
-    const IStore inner = istore_carve(s_inner, CAP_INNER);
-    const IStore outer = istore_carve(s_outer, CAP_OUTER);
+    static double s_spill[RIM_ISTORE_DOUBLES(5000) + RIM_ISTORE_DOUBLES(4096)];
+    const IStore inner = istore_carve(s_inner, CAP_INNER, s_spill, 5000);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER, s_spill + RIM_ISTORE_DOUBLES(5000), 4096);
     if (g.lane == 0) s_qpark.ctr = WaveCounters{0, 0, 0};
     wv_sync();
 
