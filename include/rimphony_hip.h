@@ -167,6 +167,7 @@ int rimphony_gamma_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1
  *   family 2: x^2 * (p0 + x * p1)                  family 3: 1 / sqrt(|x - p0| + p1)
+ *   family 4: p1 * |frac(x * p0) - 1/2|  (triangle wave: forces long subinterval lists)
  * Arrays of `count` problems; outputs result, abserr, status, size. */
 int rimphony_qag_selftest_device(rimphony_ctx *ctx, size_t count, const int32_t *d_family,
                                  const double *d_p0, const double *d_p1, const double *d_a, const double *d_b,

@@ -380,7 +380,8 @@ static double selftest_integrand(double x, void *ctx)
     case 0: { const double u = (x - c->p0) * c->p1; return 1. / (1. + u * u); }
     case 1: return m_sqrt(m_fabs(x - c->p0)) * c->p1;
     case 2: return x * x * (c->p0 + x * c->p1);
-    default: return 1. / m_sqrt(m_fabs(x - c->p0) + c->p1);
+    case 3: return 1. / m_sqrt(m_fabs(x - c->p0) + c->p1);
+    default: { const double u = x * c->p0; return c->p1 * m_fabs((u - rim_floor(u)) - 0.5); }
     }
 }
 

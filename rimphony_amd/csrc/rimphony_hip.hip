@@ -410,7 +410,8 @@ __device__ inline double selftest_integrand(int family, double p0, double p1, do
     case 0: { const double u = (x - p0) * p1; return 1. / (1. + u * u); }
     case 1: return rim_sqrt(rim_fabs(x - p0)) * p1;
     case 2: return x * x * (p0 + x * p1);
-    default: return 1. / rim_sqrt(rim_fabs(x - p0) + p1);
+    case 3: return 1. / rim_sqrt(rim_fabs(x - p0) + p1);
+    default: { const double u = x * p0; return p1 * rim_fabs((u - rim_floor(u)) - 0.5); }   // triangle wave: long lists
     }
 }
 

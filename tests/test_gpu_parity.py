@@ -102,18 +102,29 @@ def test_qag_selftest_bit_exact(gpu_ctx, oracle):
     b = a + np.exp(rng.uniform(-2, 3, N))
     p0 = a + (b - a) * rng.uniform(-0.2, 1.2, N)
     p1 = np.exp(rng.uniform(-4, 6, N))
-    for (epsabs, epsrel, limit) in [(0., 1e-3, 1000), (0., 1e-8, 1000), (1e-10, 0., 50), (0., 1e-12, 200)]:
+    for (epsabs, epsrel, limit) in [(0., 1e-3, 1000), (0., 1e-8, 1000), (1e-10, 0., 50), (0., 1e-12, 200), (0., 1e-13, 700)]:
         res, err, qst, size = gpu_ctx.qag_selftest(fam, p0, p1, a, b, epsabs, epsrel, limit)
         ref = [oracle_bind.qag_selftest(oracle, fam[i], p0[i], p1[i], a[i], b[i], epsabs, epsrel, limit) for i in range(N)]
         rst = np.array([r[0] for r in ref]); rres = np.array([r[1] for r in ref])
         rerr = np.array([r[2] for r in ref]); rsz = np.array([r[3] for r in ref])
-        # the device store holds 256 intervals; beyond that it reports ESTORE (1001)
-        fits = rsz < 256
-        assert (qst[fits] == rst[fits]).all(), (epsrel, np.flatnonzero(qst[fits] != rst[fits])[:5])
-        assert (size[fits] == rsz[fits]).all()
-        report_mismatch("qag result eps=%g" % epsrel, res[fits], rres[fits])
-        report_mismatch("qag abserr eps=%g" % epsrel, err[fits], rerr[fits])
-        assert (qst[~fits] == 1001).all()
+        # lists longer than the 256-entry LDS store spill to global memory: every size up to the
+        # GSL limit must agree
+        assert (qst == rst).all(), (epsrel, np.flatnonzero(qst != rst)[:5])
+        assert (size == rsz).all()
+        report_mismatch("qag result eps=%g" % epsrel, res, rres)
+        report_mismatch("qag abserr eps=%g" % epsrel, err, rerr)
+    # long subinterval lists (beyond the LDS store): triangle waves with many kinks
+    M = 64
+    fam = np.full(M, 4, dtype=np.int32)
+    a = rng.uniform(-1, 0, M); b = a + rng.uniform(2, 6, M)
+    p0 = rng.uniform(20, 120, M); p1 = np.exp(rng.uniform(-2, 2, M))
+    res, err, qst, size = gpu_ctx.qag_selftest(fam, p0, p1, a, b, 0., 1e-6, 5000)
+    ref = [oracle_bind.qag_selftest(oracle, 4, p0[i], p1[i], a[i], b[i], 0., 1e-6, 5000) for i in range(M)]
+    rsz = np.array([r[3] for r in ref])
+    assert rsz.max() > 300, rsz.max()      # well past the 256-entry LDS part
+    assert (qst == np.array([r[0] for r in ref])).all() and (size == rsz).all()
+    report_mismatch("qag long-list result", res, np.array([r[1] for r in ref]))
+    report_mismatch("qag long-list abserr", err, np.array([r[2] for r in ref]))
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
