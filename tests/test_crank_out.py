@@ -1,0 +1,58 @@
+"""The crank-out TSV format (examples/crank-out-pitchypl.rs:139-194, crank-out-pitchykappa.rs:165-216)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from rimphony_amd import crank_out
+
+
+def test_rust_exponent_format():
+    # Rust `{:.16e}`: no '+', no zero padding of the exponent
+    assert crank_out.rust_e16(1.0) == "1.0000000000000000e0"
+    assert crank_out.rust_e16(1234.5) == "1.2345000000000000e3"
+    assert crank_out.rust_e16(-2.5e-7) == "-2.4999999999999999e-7"   # exact decimal expansion, correctly rounded
+    assert crank_out.rust_e16(6.02e23) == "6.0200000000000000e23"
+    assert crank_out.rust_e16(float("nan")) == "NaN"
+    assert crank_out.rust_e16(float("inf")) == "inf"
+    assert float(crank_out.rust_e16(0.1 + 0.2)) == 0.1 + 0.2     # 17 significant digits round-trip
+
+
+def test_driver_writes_reference_format(tmp_path, oracle):
+    """Run the pitchy-pl driver with the per-block compute replaced by the oracle (CPU)."""
+    import oracle_bind
+    out = tmp_path / "train.txt"
+
+    def compute(kind, s, th, params):
+        return oracle_bind.batch(oracle, kind, s, th, params, 0xFF, nthreads=8)
+
+    n = crank_out.run("pitchypl", str(out), [1.0, 100.0, 0.2, 1.4, 2.0, 3.0, 0.0, 1.0], count=5, block=3, seed=1,
+                      compute=compute)
+    assert n == 5
+    lines = out.read_text().strip().split("\n")
+    assert lines[0] == crank_out.HEADER_PITCHYPL
+    assert len(lines) == 6
+    for ln in lines[1:]:
+        f = ln.split("\t")
+        assert len(f) == 13
+        vals = [float(x) if x != "NaN" else math.nan for x in f]
+        assert 1.0 <= vals[0] <= 100.0 and 0.2 <= vals[1] <= 1.4 and 2.0 <= vals[2] <= 3.0 and 0.0 <= vals[3] <= 1.0
+        assert all(math.isfinite(v) for v in vals[5:11])          # six Symphony coefficients
+        assert "e+" not in ln and "e-0" not in ln
+    assert not os.path.exists(str(out) + ".pending")
+    # second start appends and re-writes the header, as the reference does
+    crank_out.run("pitchypl", str(out), [1.0, 100.0, 0.2, 1.4, 2.0, 3.0, 0.0, 1.0], count=1, block=3, seed=2, compute=compute)
+    lines = out.read_text().strip().split("\n")
+    assert len(lines) == 8 and lines[6] == crank_out.HEADER_PITCHYPL
+
+
+@pytest.mark.gpu
+def test_driver_on_gpu(tmp_path, gpu_ctx):
+    from rimphony_amd import api
+    out = tmp_path / "k.txt"
+    crank_out.run("pitchykappa", str(out), [1.0, 50.0, 0.3, 1.3, 2.0, 4.0, 3.0, 10.0, 0.0, 2.0], count=6, block=4, seed=3,
+                  compute=lambda kind, s, th, params: gpu_ctx.compute_batch(kind, s, th, params, api.SLOTS_ALL))
+    lines = out.read_text().strip().split("\n")
+    assert lines[0] == crank_out.HEADER_PITCHYKAPPA and len(lines) == 7
+    assert all(len(ln.split("\t")) == 14 for ln in lines[1:])
