@@ -58,12 +58,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
+    # Rehearsal switch for 1-GPU boxes: RIMPHONY_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo
+    # (the gather then goes through host memory).  The real multi-GPU run uses RCCL ("nccl"), one GPU per rank.
+    rehearse = os.environ.get("RIMPHONY_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
-    ctx = api.Context(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ctx = api.Context(dev_index)
+    dev = torch.device("cuda", dev_index)
     kind, mask, _, _, _ = workload.make_batch(args.config, 1)
     nsel = bin(mask & 0x3F).count("1")
 
@@ -92,7 +99,8 @@ def main():
         s, th, params = shards[i]
         out, _ = ctx.compute_batch_device(kind, s, th, params, mask)
         if distributed:
-            sharding.gather_table(out, P * world, rank, world, dst=0)   # RCCL gather of the output table
+            # RCCL gather of the output table (host tensors in the gloo rehearsal)
+            sharding.gather_table(out.cpu() if rehearse else out, P * world, rank, world, dst=0)
         if record:
             kernel_ms.append(ctx.last_symphony_ms())        # HIP events on the launch stream
             samples.append(ctx.last_work()["samples"])
@@ -108,7 +116,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
