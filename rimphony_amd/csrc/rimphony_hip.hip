@@ -318,17 +318,29 @@ __global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
 // ------------------------------------------------------------------------------
 #define ORDER_BUCKETS 32
 
-__device__ __forceinline__ int order_bucket(double s)
+__device__ __forceinline__ int order_bucket(double s, double theta, const double *gmin, size_t i)
 {
+    // Points whose 30 discrete harmonics all lie below gamma_min (power-law families) start the n
+    // integration from zero and must resolve the onset at gamma_min inside one wide chunk: they are
+    // 100-1000x the mean cost (and usually end in a GSL round-off failure, as in the reference).
+    // They go first.
+    if (gmin) {
+        double sn, cs;
+        rim_sincos(theta, &sn, &cs);
+        const double n = rim_floor(s * rim_fabs(sn) + 30.);
+        const double nos = n / s;
+        const double gp = (nos + rim_fabs(cs) * rim_sqrt(nos * nos - sn * sn)) / (sn * sn);
+        if (gp < gmin[i]) return 0;
+    }
     const int e = (int) ((rim_bits(s) >> 52) & 0x7ff) - 1023;     // floor(log2 s) for normal s
-    int b = 16 - e;                                                 // large s -> small bucket index
-    return b < 0 ? 0 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
+    int b = 17 - e;                                                 // large s -> small bucket index
+    return b < 1 ? 1 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
 }
 
-__global__ void order_hist_kernel(const double *s, size_t n, unsigned *hist)
+__global__ void order_hist_kernel(const double *s, const double *theta, const double *gmin, size_t n, unsigned *hist)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[order_bucket(s[i])], 1u);
+    if (i < n) atomicAdd(&hist[order_bucket(s[i], theta[i], gmin, i)], 1u);
 }
 
 __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, one thread
@@ -339,10 +351,11 @@ __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, 
     }
 }
 
-__global__ void order_scatter_kernel(const double *s, size_t n, unsigned *offsets, unsigned *perm)
+__global__ void order_scatter_kernel(const double *s, const double *theta, const double *gmin, size_t n,
+                                     unsigned *offsets, unsigned *perm)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i])], 1u)] = (unsigned) i;
+    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i], theta[i], gmin, i)], 1u)] = (unsigned) i;
 }
 
 // fills the slots that were not selected (or not yet available) with NaN
@@ -691,9 +704,10 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         unsigned *hist = c->d_perm + c->norm_cap;
         const unsigned nb = (unsigned) ((n + 255) / 256);
         HIP_TRY(hipMemsetAsync(hist, 0, ORDER_BUCKETS * sizeof(unsigned), st));
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, d_s, n, hist);
+        const double *gmin = (kind == RIMPHONY_POWER_LAW) ? pp.p[1] : (kind == RIMPHONY_PITCHY_PL) ? pp.p[2] : nullptr;
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, d_s, d_theta, gmin, n, hist);
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, st, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, d_s, n, hist, c->d_perm);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, d_s, d_theta, gmin, n, hist, c->d_perm);
         HIP_TRY(hipGetLastError());
         a.perm = c->d_perm;
     }
