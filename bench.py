@@ -5,8 +5,12 @@ Workload (BASELINE.json configs[1]): power-law distribution, the 1e6-point
 synthetic table of random (s, theta, p, gamma_min) defined in
 rimphony_amd/workload.py, coefficients j_I and alpha_I, fp64.  A "step" is one
 pass of the hot path (full_calculation + the selected coefficients) over one
-batch of `--points` consecutive table rows PER GPU; successive steps walk
-through the table.  With N GPUs the step's global batch of N*points rows is
+batch of `--points` consecutive table rows PER GPU (default 262144, i.e. about a
+quarter of the table per launch); successive steps walk through the table.  Steps
+are large on purpose: the table contains rare points that are 100-1000x the mean
+cost (the reference would print "SLOW" for them, tests/symphony.rs:63-67); one such
+point keeps a single wave busy for ~8 s, which a ~9 s launch hides and a 2 s launch
+does not ("tail").  With N GPUs the step's global batch of N*points rows is
 sharded interleaved (row i -> rank i mod N, no data-path collective during
 compute) and the output table is gathered to rank 0 with one RCCL gather inside
 the timed region.  Inputs are resident in HBM before the timed region starts.
@@ -41,9 +45,9 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=65536, help="table rows per GPU per step")
+    ap.add_argument("--points", type=int, default=262144, help="table rows per GPU per step")
     ap.add_argument("--config", default="cfg2_powerlaw_jI_aI")
     ap.add_argument("--cpu-sample", type=int, default=512, help="points of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
