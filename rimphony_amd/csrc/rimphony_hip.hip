@@ -74,6 +74,7 @@ __device__ inline double hyperg_2F1_at_1(double a, double b, double c)
 }
 
 struct ParamPtrs { const double *p[5]; };
+struct AssistSlot;
 
 template <int KIND>
 __device__ inline void load_params(const ParamPtrs &pp, size_t i, DistParams &d)
@@ -155,12 +156,92 @@ struct SymArgs {
     unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
     const unsigned *perm;           // task order (expensive points first) or null
     double *spill;                  // [gridDim.x][SPILL_DOUBLES_PER_WAVE] wave-private global store overflow
+    struct AssistSlot *board;       // [gridDim.x] cooperative-tail board (null: cooperation off)
+    unsigned *board_flags;          // [0] task queue exhausted, [1] waves that still own / may fetch a task
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
 };
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
 __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
+
+// ---- cooperative tail: the assist board ---------------------------------------------------
+//
+// Per-task cost has a heavy tail (rare points are 100-1000x the mean; the reference prints
+// "SLOW" for them).  With one wave per task, the end of a launch would be a few waves grinding
+// through such tasks while the rest of the chip idles.  Once the task queue has run dry, a wave
+// that still owns a task therefore PUBLISHES each batch of (n, lobe) requests of its state machine
+// on a slot of a board in global memory, and waves without a task claim individual requests,
+// evaluate the gamma-integral and write the value back.  Every request is a pure function of
+// (point, coefficient, n, lobe), so who evaluates it cannot change a bit of the result.
+//
+// Protocol (placement-independent, agent-scope release/acquire, every spin bounded):
+//   slot.claim = (seq << 32) | next      next = 0xffffffff: closed
+//   owner:  write requests -> s_waitcnt -> release fence -> s_waitcnt -> claim = (seq << 32) | 0
+//   anyone: c = load(claim); k = first request lane >= next(c) in mask; CAS(claim, c, c.next = k + 1)
+//           a successful CAS proves the batch `seq` was still open, so the request data read after
+//           the acquire fence belonged to it and stays valid until this claimer reports `done`
+//   result: res[k], status[k] -> s_waitcnt -> release fence -> s_waitcnt -> atomicAdd(done)
+//   owner:  poll done == popcount(mask) -> acquire fence -> read res[] -> claim = closed
+struct AssistSlot {
+    unsigned long long claim;
+    unsigned long long mask;
+    unsigned long long point;
+    unsigned done;
+    int slot;
+    double req_n[64];
+    double res[64];
+    int req_lobe[64];
+    int res_status[64];
+};
+
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v)
+{
+    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (v >> 32)) << 32) |
+           (unsigned) __builtin_amdgcn_readfirstlane((int) (v & 0xffffffffull));
+}
+
+// Claim the next unevaluated request of batch `seq` on `slot`; -1 if there is none (or the batch is over).
+__device__ __forceinline__ int assist_claim(AssistSlot *slot, unsigned seq, unsigned long long mask, int lane)
+{
+    int k = -1;
+    if (lane == 0) {
+        for (int tries = 0; tries < 4096; tries++) {
+            const unsigned long long c = __hip_atomic_load(&slot->claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned nxt = (unsigned) (c & 0xffffffffull);
+            if ((unsigned) (c >> 32) != seq || nxt >= 64u) break;
+            const unsigned long long rest = mask >> nxt;
+            if (rest == 0) break;
+            const int kb = (int) nxt + __builtin_ffsll((long long) rest) - 1;
+            unsigned long long expect = c;
+            const unsigned long long want = ((unsigned long long) seq << 32) | (unsigned) (kb + 1);
+            if (__hip_atomic_compare_exchange_strong(&slot->claim, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) { k = kb; break; }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(k);
+}
+
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int KIND>
+__device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slot, SymPoint &pt, DistParams &d, double &norm)
+{
+    pt.s = uni(a.s[i]);
+    rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
+    pt.sin_th = uni(pt.sin_th);
+    pt.cos_th = uni(pt.cos_th);
+    pt.coeff = uni(c_slot_coeff[slot]);
+    pt.stokes = uni(c_slot_stokes[slot]);
+    load_params<KIND>(a.pp, i, d);
+    norm = uni(a.norm[i]);
+    dist_prepare<KIND>(d, norm);
+#pragma unroll
+    for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
+    d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
+    d.inv_kappa_width = uni(d.inv_kappa_width);
+    d.neg_inverse_t = uni(d.neg_inverse_t);
+}
 
 template <int KIND>
 __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
@@ -170,58 +251,240 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
     __shared__ TaskState s_park;
     const GKLane g = gk_lane_init(s_tab);
+    const int lane = g.lane;
     double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
     const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
     const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
+    AssistSlot *const my = a.board + blockIdx.x;
+    unsigned *const flag_exhausted = a.board_flags;
+    unsigned *const flag_active = a.board_flags + 1;
+    const unsigned nboard = gridDim.x;
+    unsigned seq = 0;                      // sequence number of this wave's published batches
+
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
+    SymPoint pt;                           // context of the requests being evaluated (own task or a helped one)
+    DistParams d;
+    // The own task's state lives in LDS (s_park) between the three places that touch it, so that it
+    // never occupies registers while the integrand runs.
+    size_t own_i = 0;
+    int own_slot = 0;
+    bool have_task = false, helper = false;
+    unsigned scan_rot = blockIdx.x;
+
     for (;;) {
-        const unsigned long long t = wave_next_task(a.queue, g.lane);
-        if (t >= ntasks) break;
-        // slot-major within a point: consecutive tasks share the point's inputs in L2
-        const size_t seq = (size_t) (t / (unsigned) a.nslots);
-        const size_t i = a.perm ? (size_t) a.perm[seq] : seq;
-        const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
+        SymBatch B;
+        B.req_n = 0.; B.req_lobe = 0; B.req_active = false; B.n_req = 0; B.phase = PH_DONE;
+        AssistSlot *src = my;
+        unsigned src_seq = 0;
+        unsigned long long mask = 0;
+        bool shared = false;
 
-        SymPoint pt;
-        pt.s = uni(a.s[i]);
-        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
-        pt.sin_th = uni(pt.sin_th);
-        pt.cos_th = uni(pt.cos_th);
-        pt.coeff = uni(c_slot_coeff[slot]);
-        pt.stokes = uni(c_slot_stokes[slot]);
+        if (!helper) {
+            // ---------- owner: next batch of the current task (fetching a task first if needed) ----------
+            if (!have_task) {
+                const unsigned long long t = wave_next_task(a.queue, lane);
+                if (t >= ntasks) {
+                    helper = true;
+                    if (lane == 0) {
+                        __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (!a.board) break;     // cooperation disabled
+                    continue;
+                }
+                const size_t seqidx = (size_t) (t / (unsigned) a.nslots);
+                own_i = a.perm ? (size_t) a.perm[seqidx] : seqidx;
+                own_slot = a.slot[(int) (t % (unsigned) a.nslots)];
+                double norm;
+                load_context<KIND>(a, own_i, own_slot, pt, d, norm);
+                if (lane == 0) {
+                    s_qpark.hb = (a.heartbeat && t == a.hb_task) ? a.heartbeat : nullptr;
+                    if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
+                }
+                __syncthreads();
+                if (!(norm == norm)) {
+                    if (lane == 0) {
+                        a.out[own_i * 8 + own_slot] = RIM_NAN;
+                        if (a.status) a.status[own_i * 8 + own_slot] = ST_NORM_FAIL | ST_NONFINITE;
+                    }
+                    continue;
+                }
+                TaskState T0;
+                sym_begin(pt, T0);
+                if (lane == 0) s_park = T0;
+                __syncthreads();
+                have_task = true;
+            }
+            bool finished;
+            {
+                TaskState T = s_park;
+                task_uniformize(T);
+                if (T.phase != PH_DONE) sym_post(pt, g, outer, T, B);
+                finished = T.phase == PH_DONE;
+                if (finished) {
+                    int st = 0;
+                    const double val = sym_result(pt, T, st);
+                    if (lane == 0) {
+                        a.out[own_i * 8 + own_slot] = val;
+                        if (a.status) a.status[own_i * 8 + own_slot] = st;
+                        if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
+                    }
+                } else {
+                    __syncthreads();              // everyone has read s_park
+                    if (lane == 0) s_park = T;    // state after posting (batch counter, picked interval)
+                }
+            }
+            if (finished) { have_task = false; continue; }
+            mask = wv_ballot(B.req_active);
 
-        DistParams d;
-        load_params<KIND>(a.pp, i, d);
-        const double norm = uni(a.norm[i]);
-        dist_prepare<KIND>(d, norm);
-#pragma unroll
-        for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
-        d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
-        d.inv_kappa_width = uni(d.inv_kappa_width);
-        d.neg_inverse_t = uni(d.neg_inverse_t);
+            // publish the batch when other waves have nothing left to do
+            unsigned ex = 0;
+            if (lane == 0 && a.board) ex = __hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ex = (unsigned) __builtin_amdgcn_readfirstlane((int) ex);
+            shared = ex != 0 && __builtin_popcountll(mask) >= 2;
+            if (shared) {
+                seq += 1;
+                src_seq = seq;
+                my->req_n[lane] = B.req_n;
+                my->req_lobe[lane] = B.req_lobe;
+                if (lane == 0) {
+                    my->mask = mask;
+                    my->point = (unsigned long long) own_i;
+                    my->slot = own_slot;
+                    my->done = 0;
+                }
+                drain_vmem();
+                __syncthreads();
+                if (lane == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    drain_vmem();
+                    __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else {
+            // ---------- helper: find a published batch ----------
+            int found = -1;
+            unsigned long long cw = 0;
+            for (unsigned base = 0; base < nboard && found < 0; base += 64) {
+                const unsigned j = (scan_rot + base + (unsigned) lane) % nboard;
+                unsigned long long c = 0xffffffffffffffffull;
+                if (base + (unsigned) lane < nboard)
+                    c = __hip_atomic_load(&a.board[j].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool open = (unsigned) (c & 0xffffffffull) < 64u;
+                const unsigned long long om = wv_ballot(open);
+                if (om) {
+                    const int src_lane = __builtin_ffsll((long long) om) - 1;
+                    found = (int) ((scan_rot + base + (unsigned) src_lane) % nboard);
+                    cw = bcast_u64(__shfl(c, src_lane));
+                }
+            }
+            if (found < 0) {
+                unsigned act = 1;
+                if (lane == 0) act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
+                if (act == 0) break;       // every task is finished
+                __builtin_amdgcn_s_sleep(64);
+                scan_rot += 64;
+                continue;
+            }
+            src = a.board + found;
+            src_seq = (unsigned) (cw >> 32);
+            if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_vmem();
+            __syncthreads();
+            mask = bcast_u64(src->mask);
+            shared = true;
+            // context of the helped task is loaded after the first successful claim (below)
+        }
 
-        if (g.lane == 0) {
-            s_qpark.hb = (a.heartbeat && t == a.hb_task) ? a.heartbeat : nullptr;
-            if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
+        // ---------- evaluate requests of `src` (the integrand lives here, once) ----------
+        int batch_status = 0;
+        double gval = 0.;
+        bool ctx_loaded = !helper;
+        unsigned long long local_mask = mask;
+        for (;;) {
+            int k;
+            if (shared) {
+                k = assist_claim(src, src_seq, mask, lane);
+            } else {
+                k = local_mask ? __builtin_ffsll((long long) local_mask) - 1 : -1;
+                local_mask &= local_mask - 1;
+            }
+            if (k < 0) break;
+            double n;
+            int lb;
+            if (helper) {
+                if (!ctx_loaded) {
+                    double norm;
+                    const size_t hi = (size_t) bcast_u64(src->point);
+                    const int hslot = __builtin_amdgcn_readfirstlane(src->slot);
+                    load_context<KIND>(a, hi, hslot, pt, d, norm);
+                    ctx_loaded = true;
+                }
+                n = uni(src->req_n[k]);
+                lb = __builtin_amdgcn_readfirstlane(src->req_lobe[k]);
+            } else {
+                n = readlane_d(B.req_n, k);
+                lb = wv_readlane(B.req_lobe, k);
+            }
+            if (lane == 0 && s_qpark.hb) {
+                hb_store(s_qpark.hb + 8, (unsigned long long) k);
+                hb_store(s_qpark.hb + 9, rim_bits(n));
+            }
+            int st = 0;
+            const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, st);
+            if (shared) {
+                if (lane == 0) {
+                    src->res[k] = val;
+                    src->res_status[k] = st;
+                    drain_vmem();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    drain_vmem();
+                    __hip_atomic_fetch_add(&src->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (lane == k) gval = val;
+                batch_status |= st;
+            }
+        }
+        if (helper) { scan_rot += 1; continue; }
+
+        // ---------- owner: collect a shared batch, then the continuation ----------
+        if (shared) {
+            const unsigned want = (unsigned) __builtin_popcountll(mask);
+            bool complete = false;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                unsigned dn = 0;
+                if (lane == 0) dn = __hip_atomic_load(&my->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn = (unsigned) __builtin_amdgcn_readfirstlane((int) dn);
+                if (dn >= want) { complete = true; break; }
+                if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_vmem();
+            __syncthreads();
+            int stl = 0;
+            if ((mask >> lane) & 1ull) { gval = my->res[lane]; stl = my->res_status[lane]; }
+            if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
+            if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
+            if (!complete) { batch_status |= ST_CHUNK_CAP; gval = RIM_NAN; }
+            if (lane == 0)
+                __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | 0xffffffffull, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-
-        double val;
-        int st = 0;
-        if (!(norm == norm)) {
-            val = RIM_NAN;
-            st = ST_NORM_FAIL | ST_NONFINITE;
-        } else {
-            val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
-        }
-        if (g.lane == 0 && s_qpark.hb) hb_store(s_qpark.hb + 11, 400ull);
-        if (g.lane == 0) {
-            a.out[i * 8 + slot] = val;
-            if (a.status) a.status[i * 8 + slot] = st;
-            if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
+        {
+            TaskState T = s_park;
+            task_uniformize(T);
+            sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
+            __syncthreads();
+            if (lane == 0) s_park = T;
+            __syncthreads();
         }
     }
 
@@ -231,6 +494,11 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         atomicAdd(a.queue + 2, s_qpark.ctr.steps);
         atomicAdd(a.queue + 3, s_qpark.ctr.inner_qags);
     }
+}
+
+__global__ void board_init_kernel(unsigned *flags, unsigned active)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { flags[0] = 0; flags[1] = active; }
 }
 
 // ------------------------------------------------------------------------------
@@ -467,6 +735,8 @@ struct rimphony_ctx {
     unsigned *d_perm;               // [norm_cap] task order + ORDER_BUCKETS histogram words behind it
     double *d_spill;                // [spill_waves][SPILL_DOUBLES_PER_WAVE]
     size_t spill_waves;
+    AssistSlot *d_board;            // [board_slots] + flags behind
+    size_t board_slots;
     size_t norm_cap;
     // staging for the host-buffer entry point
     double *d_in;
@@ -547,6 +817,7 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     if (c->d_norm) (void) hipFree(c->d_norm);
     if (c->d_perm) (void) hipFree(c->d_perm);
     if (c->d_spill) (void) hipFree(c->d_spill);
+    if (c->d_board) (void) hipFree(c->d_board);
     if (c->d_in) (void) hipFree(c->d_in);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_status) (void) hipFree(c->d_status);
@@ -636,11 +907,25 @@ template <int KIND>
 static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
-    const unsigned grid = persistent_grid(c, ntasks, 4 * RIM_SYM_WAVES);
+    // more waves than tasks on small batches: the surplus waves start as helpers right away
+    const unsigned long long want_waves = ntasks > (1ull << 40) ? ntasks : ntasks * 64ull;
+    const unsigned grid = persistent_grid(c, want_waves, 4 * RIM_SYM_WAVES);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
+    if (c->board_slots < grid) {
+        if (c->d_board) (void) hipFree(c->d_board);
+        c->d_board = nullptr;
+        c->board_slots = 0;
+        if (hipMalloc(&c->d_board, (size_t) grid * sizeof(AssistSlot) + 64) != hipSuccess) return RIMPHONY_ENOMEM;
+        c->board_slots = grid;
+    }
     SymArgs b = a;
     b.spill = c->d_spill;
+    b.board = c->d_board;
+    b.board_flags = (unsigned *) (c->d_board + c->board_slots);
+    // every claim word starts closed (all ones); flags: not exhausted, `grid` active waves
+    HIP_TRY(hipMemsetAsync(c->d_board, 0xFF, (size_t) grid * sizeof(AssistSlot), st));
+    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(64), 0, st, b.board_flags, grid);
     HIP_TRY(hipEventRecord(c->ev_start, st));
     hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
     HIP_TRY(hipGetLastError());
@@ -700,6 +985,8 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     a.queue = c->d_queue;
     a.perm = nullptr;
     a.spill = nullptr;
+    a.board = nullptr;
+    a.board_flags = nullptr;
     if (n > 4096 && n < 0xffffffffull) {
         unsigned *hist = c->d_perm + c->norm_cap;
         const unsigned nb = (unsigned) ((n + 255) / 256);

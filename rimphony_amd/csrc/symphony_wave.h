@@ -89,7 +89,7 @@ struct TaskState {
     double ni_ans, contrib, delta_n, incr, n_start;   // n_integration locals
     double dr_h, dr_r0, dr_err;                   // deriv_central locals
     double qa, qb;                                // chunk limits
-    long long disc_next;                          // next discrete harmonic to post
+    long long disc_next, disc_hi;                 // next discrete harmonic to post, end of the discrete range
     int chunks, lobe, phase, ni_failed, status, batches;
     QagState oq;                                  // outer QAG over n
 };
@@ -101,6 +101,7 @@ __device__ __forceinline__ void task_uniformize(TaskState &T)
     T.dr_h = uni(T.dr_h); T.dr_r0 = uni(T.dr_r0); T.dr_err = uni(T.dr_err);
     T.qa = uni(T.qa); T.qb = uni(T.qb);
     T.disc_next = (long long) rim_bits(uni(rim_frombits((unsigned long long) T.disc_next)));
+    T.disc_hi = (long long) rim_bits(uni(rim_frombits((unsigned long long) T.disc_hi)));
     T.chunks = uni(T.chunks); T.lobe = uni(T.lobe); T.phase = uni(T.phase); T.ni_failed = uni(T.ni_failed);
     T.status = uni(T.status); T.batches = uni(T.batches);
     qag_uniformize(T.oq);
@@ -123,27 +124,81 @@ __device__ __forceinline__ SymOrder uniform_order(SymOrder so)
     return so;
 }
 
-// diagnostics: progress marker in heartbeat word 11
-#define RIM_HB_STAGE(code) do { if (lane == 0 && qpark->hb) hb_store(qpark->hb + 11, (unsigned long long) (code)); } while (0)
+// ---- the coefficient as a resumable computation -------------------------------------------
+//
+//   sym_begin    initialise the task state
+//   sym_post     phase -> a batch of up to 62 (n, lobe) requests, one per lane
+//   (the caller evaluates the requests: sym_eval_request, the only place the integrand lives)
+//   sym_consume  continuation of the posting phase on the 62 results; T.phase == PH_DONE at the end
+//   sym_result   final NaN policy + dimensional prefactor
+//
+// Splitting it this way lets the kernel hand the requests of a batch to OTHER waves once the task
+// queue has run dry (cooperative tail, rimphony_hip.hip) while keeping one copy of the integrand.
 
-template <int KIND>
-__device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
-                                              const IStore &inner, const IStore &outer, TaskState *park,
-                                              QagPark *qpark, int &status_out)
+struct SymBatch {
+    double req_n;        // per lane
+    int req_lobe;        // per lane
+    bool req_active;     // per lane
+    int n_req;           // uniform: requests of the discrete / deriv phases (lanes 0 .. n_req-1)
+    int phase;           // uniform: the phase that posted the batch
+};
+
+#define RIM_N_MAX 30.
+
+// n_integration prologue (symphony.rs:197-215)
+__device__ __forceinline__ void sym_start_lobe(const SymPoint &pt, TaskState &T, int which)
 {
-    const double N_MAX = 30.;
-    const int lane = g.lane;
-    const bool is_v = pt.stokes == STOKES_V;
+    const double n_minus = pt.s * rim_fabs(pt.sin_th);
+    T.lobe = which;
+    T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.chunks = 0;
+    T.ni_failed = 0;
+    T.n_start = rim_floor(n_minus + 1. + RIM_N_MAX);
+    if (pt.s < 10.) { T.delta_n = 1.; T.incr = 2.; }
+}
 
+// What follows once the current lobe's n_integration has ended (symphony.rs:127-146).
+__device__ __forceinline__ int sym_end_of_lobe(const SymPoint &pt, TaskState &T)
+{
+    const double c = T.ni_failed ? RIM_NAN : T.ni_ans;
+    T.ans += c;
+    if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; return PH_DONE; }
+    if (pt.stokes == STOKES_V && T.lobe == 0) {
+        sym_start_lobe(pt, T, 1);
+        return PH_DERIV1;   // the caller re-checks the while condition for the new lobe
+    }
+    return PH_DONE;
+}
+
+// while-condition of n_integration (symphony.rs:225) + chunk cap
+__device__ __forceinline__ int sym_chunk_loop_head(const SymPoint &pt, TaskState &T)
+{
+    for (;;) {
+        if (!(rim_fabs(T.contrib) >= rim_fabs(T.ni_ans / 1e5))) {
+            if (sym_end_of_lobe(pt, T) == PH_DONE) return PH_DONE;
+            continue;
+        }
+        if (++T.chunks > RIM_MAX_CHUNKS) {
+            T.status |= ST_CHUNK_CAP;
+            T.ni_failed = 1;
+            if (sym_end_of_lobe(pt, T) == PH_DONE) return PH_DONE;
+            continue;
+        }
+        T.dr_h = 1e-10 * T.n_start;
+        return PH_DERIV1;
+    }
+}
+
+__device__ __forceinline__ void sym_begin(const SymPoint &pt, TaskState &T)
+{
     const double n_minus = pt.s * rim_fabs(pt.sin_th);
     const long long n_lo = sat_i64(n_minus + 1.);
-    const long long n_hi = sat_i64(n_minus + 1. + N_MAX);
+    const long long n_hi = sat_i64(n_minus + 1. + RIM_N_MAX);
 
-    TaskState T;
     T.ans = 0.;
     T.status = ST_OK;
     T.phase = PH_DISCRETE;
     T.disc_next = n_lo;
+    T.disc_hi = n_hi;
     T.lobe = 0;
     T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.n_start = 0.;
     T.chunks = 0;
@@ -153,260 +208,240 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
     T.qa = 0.; T.qb = 0.;
     qag_begin(T.oq, 0., 1e-3, 1000);
 
-    // n_integration prologue (symphony.rs:197-215)
-    auto start_lobe = [&](int which) {
-        T.lobe = which;
-        T.ni_ans = 0.; T.contrib = 0.; T.delta_n = 1e5; T.incr = 10.; T.chunks = 0;
-        T.ni_failed = 0;
-        T.n_start = rim_floor(n_minus + 1. + N_MAX);
-        if (pt.s < 10.) { T.delta_n = 1.; T.incr = 2.; }
-    };
-
-    // What follows once the current lobe's n_integration has ended (symphony.rs:127-146).
-    auto end_of_lobe = [&]() -> int {
-        RIM_HB_STAGE(220);
-        const double c = T.ni_failed ? RIM_NAN : T.ni_ans;
-        T.ans += c;
-        if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; return PH_DONE; }
-        if (is_v && T.lobe == 0) {
-            start_lobe(1);
-            return PH_DERIV1;   // the caller re-checks the while condition for the new lobe
-        }
-        return PH_DONE;
-    };
-
-    // while-condition of n_integration (symphony.rs:225) + chunk cap
-    auto chunk_loop_head = [&]() -> int {
-        for (;;) {
-            if (!(rim_fabs(T.contrib) >= rim_fabs(T.ni_ans / 1e5))) {
-                if (end_of_lobe() == PH_DONE) return PH_DONE;
-                continue;
-            }
-            if (++T.chunks > RIM_MAX_CHUNKS) {
-                T.status |= ST_CHUNK_CAP;
-                T.ni_failed = 1;
-                if (end_of_lobe() == PH_DONE) return PH_DONE;
-                continue;
-            }
-            T.dr_h = 1e-10 * T.n_start;
-            return PH_DERIV1;
-        }
-    };
-
     if (n_hi <= n_lo) {
         // no discrete harmonics (only for absurd n_minus): straight to the tail
-        start_lobe(0);
-        T.phase = chunk_loop_head();
+        sym_start_lobe(pt, T, 0);
+        T.phase = sym_chunk_loop_head(pt, T);
+    }
+}
+
+// Post the batch of the current phase.  Returns false when the backstop on the number of
+// batches fired (the task is then finished with NaN).
+__device__ __forceinline__ bool sym_post(const SymPoint &pt, const GKLane &g, const IStore &outer, TaskState &T, SymBatch &B)
+{
+    const int lane = g.lane;
+    const bool is_v = pt.stokes == STOKES_V;
+    B.req_n = 0.;
+    B.req_lobe = 0;
+    B.req_active = false;
+    B.n_req = 0;
+    B.phase = T.phase;
+
+    if (++T.batches > RIM_MAX_BATCHES) {
+        T.status |= ST_CHUNK_CAP;
+        T.ans = RIM_NAN;
+        T.phase = PH_DONE;
+        return false;
     }
 
-    while (T.phase != PH_DONE) {
-        if (++T.batches > RIM_MAX_BATCHES) {
-            T.status |= ST_CHUNK_CAP;
-            T.ans = RIM_NAN;
-            break;
+    if (T.phase == PH_DISCRETE) {
+        // up to 31 harmonics per batch; for V the two lobes of a harmonic sit on adjacent lanes
+        const int per = is_v ? 2 : 1;
+        const long long remaining = T.disc_hi - T.disc_next;
+        const int cnt = remaining > 31 ? 31 : (int) remaining;
+        B.n_req = cnt * per;
+        if (lane < B.n_req) {
+            B.req_n = (double) (T.disc_next + lane / per);
+            B.req_lobe = is_v ? (lane & 1) : 0;
+            B.req_active = true;
         }
-        // ---- 1. post a batch of (n, lobe) requests, one per lane ----------------
-        double req_n = 0.;
-        int req_lobe = 0;
-        bool req_active = false;
-        int n_req = 0;
-        const int phase = T.phase;
-
-        if (phase == PH_DISCRETE) {
-            // up to 31 harmonics per batch; for V the two lobes of a harmonic sit on adjacent lanes
-            const int per = is_v ? 2 : 1;
-            const long long remaining = n_hi - T.disc_next;
-            const int cnt = remaining > 31 ? 31 : (int) remaining;
-            n_req = cnt * per;
-            if (lane < n_req) {
-                req_n = (double) (T.disc_next + lane / per);
-                req_lobe = is_v ? (lane & 1) : 0;
-                req_active = true;
-            }
-        } else if (phase == PH_DERIV1 || phase == PH_DERIV2) {
-            // central_deriv: f(x-h), f(x+h), f(x-h/2), f(x+h/2)  (deriv.c order)
-            n_req = 4;
-            if (lane < 4) {
-                const double h = T.dr_h;
-                req_n = (lane == 0) ? T.n_start - h : (lane == 1) ? T.n_start + h
-                      : (lane == 2) ? T.n_start - h / 2 : T.n_start + h / 2;
-                req_lobe = T.lobe;
-                req_active = true;
-            }
-        } else if (phase == PH_QAG_FIRST) {
-            const double center = 0.5 * (T.qa + T.qb);
-            const double hl = 0.5 * (T.qb - T.qa);
-            req_n = center + hl * g.t;
-            req_lobe = T.lobe;
-            req_active = g.node && g.half == 0;
-        } else {   // PH_QAG_BISECT
-            qag_pick(T.oq, outer, lane);
-            const double la = g.half ? T.oq.a2 : T.oq.a1;
-            const double lb = g.half ? T.oq.b2 : T.oq.b1;
-            const double center = 0.5 * (la + lb);
-            const double hl = 0.5 * (lb - la);
-            req_n = center + hl * g.t;
-            req_lobe = T.lobe;
-            req_active = g.node;
-        }
-
-        // park the uniform state in LDS while the batch runs
-        if (lane == 0) {
-            *park = T;
-            if (qpark->hb) {
-                hb_store(qpark->hb + 1, (unsigned long long) T.batches);
-                hb_store(qpark->hb + 2, (unsigned long long) phase);
-                hb_store(qpark->hb + 5, (unsigned long long) T.chunks);
-                hb_store(qpark->hb + 6, rim_bits(T.n_start));
-                hb_store(qpark->hb + 7, rim_bits(T.delta_n));
-            }
-        }
-        int batch_status = 0;
-
-        // ---- 2. evaluate the requests: the only copy of the inner QAG ------------
-        double gval = 0.;
-        {
-            unsigned long long mask = wv_ballot(req_active);
-            while (mask) {
-                const int k = __builtin_ffsll((long long) mask) - 1;
-                mask &= mask - 1;
-                const double n = readlane_d(req_n, k);
-                const int lb = wv_readlane(req_lobe, k);
-                if (lane == 0 && qpark->hb) {
-                    hb_store(qpark->hb + 8, (unsigned long long) k);
-                    hb_store(qpark->hb + 9, rim_bits(n));
-                }
-                const SymOrder so = uniform_order(sym_order(n));
-                GammaLimits L = gamma_limits(pt, n, lb);
-                L.g0 = uni(L.g0);
-                L.g1 = uni(L.g1);
-                auto f = [&](double x, bool active) -> double {
-                    return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
-                };
-                QagState iq;
-                wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, iq, qpark);
-                if (lane == 0) qpark->ctr.inner_qags += 1;
-                double val = uni(iq.result);
-                if (uni(iq.status) != QAG_SUCCESS) {
-                    val = RIM_NAN;
-                    batch_status |= ST_INNER_FAIL;
-                    if (iq.status == QAG_ESTORE) batch_status |= ST_STORE_FULL;
-                }
-                if (lane == k) gval = val;
-            }
-        }
-
-        wv_sync();
-        T = *park;
-        task_uniformize(T);
-        T.status |= uni(batch_status);
-        RIM_HB_STAGE(100 + phase);
-
-        // ---- 3. continuation of the posting phase --------------------------------
-        if (phase == PH_DISCRETE) {
-            for (int k = 0; k < n_req; k++) T.ans += readlane_d(gval, k);
-            const int per = is_v ? 2 : 1;
-            T.disc_next += n_req / per;
-            if (T.disc_next < n_hi) continue;
-            if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; break; }
-            start_lobe(0);
-            T.phase = chunk_loop_head();
-            continue;
-        }
-
-        if (phase == PH_DERIV1 || phase == PH_DERIV2) {
-            const double fm1 = readlane_d(gval, 0), fp1 = readlane_d(gval, 1);
-            const double fmh = readlane_d(gval, 2), fph = readlane_d(gval, 3);
+    } else if (T.phase == PH_DERIV1 || T.phase == PH_DERIV2) {
+        // central_deriv: f(x-h), f(x+h), f(x-h/2), f(x+h/2)  (deriv.c order)
+        B.n_req = 4;
+        if (lane < 4) {
             const double h = T.dr_h;
-            const double x = T.n_start;
-            const double r3 = 0.5 * (fp1 - fm1);
-            const double r5 = (4.0 / 3.0) * (fph - fmh) - (1.0 / 3.0) * r3;
-            const double e3 = (rim_fabs(fp1) + rim_fabs(fm1)) * RIM_DBL_EPSILON;
-            const double e5 = 2.0 * (rim_fabs(fph) + rim_fabs(fmh)) * RIM_DBL_EPSILON + e3;
-            const double dy = rim_max(rim_fabs(r3 / h), rim_fabs(r5 / h)) * (rim_fabs(x) / h) * RIM_DBL_EPSILON;
-            const double res = r5 / h;
-            const double trunc = rim_fabs((r5 - r3) / h);
-            const double round = rim_fabs(e5 / h) + dy;
-
-            if (phase == PH_DERIV1) {
-                T.dr_r0 = res;
-                T.dr_err = round + trunc;
-                if (round < trunc && (round > 0 && trunc > 0)) {
-                    T.dr_h = (1e-10 * T.n_start) * rim_pow(round / (2.0 * trunc), 1.0 / 3.0);
-                    T.phase = PH_DERIV2;
-                    continue;
-                }
-            } else {
-                const double error_opt = round + trunc;
-                if (error_opt < T.dr_err && rim_fabs(res - T.dr_r0) < 4.0 * T.dr_err) {
-                    T.dr_r0 = res;
-                    T.dr_err = error_opt;
-                }
-            }
-            const double deriv = T.dr_r0;
-
-            if (deriv == 0. || (T.contrib != 0. && rim_fabs(deriv / T.contrib) < 1e-5)) T.delta_n *= T.incr;
-            if (T.delta_n < T.n_start / T.incr) T.delta_n *= T.incr;
-
-            T.qa = T.n_start;
-            T.qb = T.n_start + T.delta_n;
-            qag_begin(T.oq, 0., 1e-3, 1000);
-            T.phase = PH_QAG_FIRST;
-            continue;
+            B.req_n = (lane == 0) ? T.n_start - h : (lane == 1) ? T.n_start + h
+                    : (lane == 2) ? T.n_start - h / 2 : T.n_start + h / 2;
+            B.req_lobe = T.lobe;
+            B.req_active = true;
         }
-
-        // outer GK31 over the values now sitting in the lanes
-        bool chunk_done;
-        if (phase == PH_QAG_FIRST) {
-            const double hl = 0.5 * (T.qb - T.qa);
-            const GKRes r = wave_gk31(gval, hl, g);
-            chunk_done = qag_after_first(T.oq, outer, lane, T.qa, T.qb, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
-                                         readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
-        } else {
-            const double la = g.half ? T.oq.a2 : T.oq.a1;
-            const double lb = g.half ? T.oq.b2 : T.oq.b1;
-            const double hl = 0.5 * (lb - la);
-            const GKRes r = wave_gk31(gval, hl, g);
-            chunk_done = qag_after_bisect(T.oq, outer, lane,
-                                          readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
-                                          readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
-        }
-        if (!chunk_done) { T.phase = PH_QAG_BISECT; continue; }
-
-        if (T.oq.status != QAG_SUCCESS) {
-            // `?` in n_integration (symphony.rs:269): the whole n integration is an Err
-            T.status |= ST_OUTER_FAIL;
-            if (T.oq.status == QAG_ESTORE) T.status |= ST_STORE_FULL;
-            T.ni_failed = 1;
-            T.phase = end_of_lobe();
-            if (T.phase != PH_DONE) T.phase = chunk_loop_head();
-            continue;
-        }
-        T.contrib = T.oq.result;
-        T.ni_ans += T.contrib;
-        T.n_start += T.delta_n;
-        if (T.n_start > 1e13) T.incr = 1.;
-        RIM_HB_STAGE(200);
-        T.phase = chunk_loop_head();
-        RIM_HB_STAGE(210 + T.phase);
+    } else if (T.phase == PH_QAG_FIRST) {
+        const double center = 0.5 * (T.qa + T.qb);
+        const double hl = 0.5 * (T.qb - T.qa);
+        B.req_n = center + hl * g.t;
+        B.req_lobe = T.lobe;
+        B.req_active = g.node && g.half == 0;
+    } else {   // PH_QAG_BISECT
+        qag_pick(T.oq, outer, lane);
+        const double la = g.half ? T.oq.a2 : T.oq.a1;
+        const double lb = g.half ? T.oq.b2 : T.oq.b1;
+        const double center = 0.5 * (la + lb);
+        const double hl = 0.5 * (lb - la);
+        B.req_n = center + hl * g.t;
+        B.req_lobe = T.lobe;
+        B.req_active = g.node;
     }
-    RIM_HB_STAGE(300);
+    return true;
+}
 
+// One request: gamma_integral(n) for the given lobe (symphony.rs:312-389).  THE integrand site.
+template <int KIND>
+__device__ __forceinline__ double sym_eval_request(const SymPoint &pt, const DistParams &dist, const GKLane &g,
+                                                   const IStore &inner, QagPark *qpark, double n, int lobe, int &st)
+{
+    const SymOrder so = uniform_order(sym_order(n));
+    GammaLimits L = gamma_limits(pt, n, lobe);
+    L.g0 = uni(L.g0);
+    L.g1 = uni(L.g1);
+    auto f = [&](double x, bool active) -> double {
+        return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
+    };
+    QagState iq;
+    wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, iq, qpark);
+    if (g.lane == 0) qpark->ctr.inner_qags += 1;
+    double val = uni(iq.result);
+    if (uni(iq.status) != QAG_SUCCESS) {
+        val = RIM_NAN;
+        st |= ST_INNER_FAIL;
+        if (iq.status == QAG_ESTORE) st |= ST_STORE_FULL;
+    }
+    return val;
+}
+
+// Continuation of the phase that posted B, given the results (lane k holds the value of request k).
+__device__ __forceinline__ void sym_consume(const SymPoint &pt, const GKLane &g, const IStore &outer, TaskState &T,
+                                            const SymBatch &B, double gval, int batch_status)
+{
+    const int lane = g.lane;
+    const int phase = B.phase;
+    const bool is_v = pt.stokes == STOKES_V;
+    T.status |= batch_status;
+
+    if (phase == PH_DISCRETE) {
+        for (int k = 0; k < B.n_req; k++) T.ans += readlane_d(gval, k);
+        const int per = is_v ? 2 : 1;
+        T.disc_next += B.n_req / per;
+        if (T.disc_next < T.disc_hi) return;
+        if (!rim_isfinite(T.ans)) { T.ans = RIM_NAN; T.phase = PH_DONE; return; }
+        sym_start_lobe(pt, T, 0);
+        T.phase = sym_chunk_loop_head(pt, T);
+        return;
+    }
+
+    if (phase == PH_DERIV1 || phase == PH_DERIV2) {
+        const double fm1 = readlane_d(gval, 0), fp1 = readlane_d(gval, 1);
+        const double fmh = readlane_d(gval, 2), fph = readlane_d(gval, 3);
+        const double h = T.dr_h;
+        const double x = T.n_start;
+        const double r3 = 0.5 * (fp1 - fm1);
+        const double r5 = (4.0 / 3.0) * (fph - fmh) - (1.0 / 3.0) * r3;
+        const double e3 = (rim_fabs(fp1) + rim_fabs(fm1)) * RIM_DBL_EPSILON;
+        const double e5 = 2.0 * (rim_fabs(fph) + rim_fabs(fmh)) * RIM_DBL_EPSILON + e3;
+        const double dy = rim_max(rim_fabs(r3 / h), rim_fabs(r5 / h)) * (rim_fabs(x) / h) * RIM_DBL_EPSILON;
+        const double res = r5 / h;
+        const double trunc = rim_fabs((r5 - r3) / h);
+        const double round = rim_fabs(e5 / h) + dy;
+
+        if (phase == PH_DERIV1) {
+            T.dr_r0 = res;
+            T.dr_err = round + trunc;
+            if (round < trunc && (round > 0 && trunc > 0)) {
+                T.dr_h = (1e-10 * T.n_start) * rim_pow(round / (2.0 * trunc), 1.0 / 3.0);
+                T.phase = PH_DERIV2;
+                return;
+            }
+        } else {
+            const double error_opt = round + trunc;
+            if (error_opt < T.dr_err && rim_fabs(res - T.dr_r0) < 4.0 * T.dr_err) {
+                T.dr_r0 = res;
+                T.dr_err = error_opt;
+            }
+        }
+        const double deriv = T.dr_r0;
+
+        if (deriv == 0. || (T.contrib != 0. && rim_fabs(deriv / T.contrib) < 1e-5)) T.delta_n *= T.incr;
+        if (T.delta_n < T.n_start / T.incr) T.delta_n *= T.incr;
+
+        T.qa = T.n_start;
+        T.qb = T.n_start + T.delta_n;
+        qag_begin(T.oq, 0., 1e-3, 1000);
+        T.phase = PH_QAG_FIRST;
+        return;
+    }
+
+    // outer GK31 over the values now sitting in the lanes
+    bool chunk_done;
+    if (phase == PH_QAG_FIRST) {
+        const double hl = 0.5 * (T.qb - T.qa);
+        const GKRes r = wave_gk31(gval, hl, g);
+        chunk_done = qag_after_first(T.oq, outer, lane, T.qa, T.qb, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
+                                     readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
+    } else {
+        const double la = g.half ? T.oq.a2 : T.oq.a1;
+        const double lb = g.half ? T.oq.b2 : T.oq.b1;
+        const double hl = 0.5 * (lb - la);
+        const GKRes r = wave_gk31(gval, hl, g);
+        chunk_done = qag_after_bisect(T.oq, outer, lane,
+                                      readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
+                                      readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+    }
+    if (!chunk_done) { T.phase = PH_QAG_BISECT; return; }
+
+    if (T.oq.status != QAG_SUCCESS) {
+        // `?` in n_integration (symphony.rs:269): the whole n integration is an Err
+        T.status |= ST_OUTER_FAIL;
+        if (T.oq.status == QAG_ESTORE) T.status |= ST_STORE_FULL;
+        T.ni_failed = 1;
+        T.phase = sym_end_of_lobe(pt, T);
+        if (T.phase != PH_DONE) T.phase = sym_chunk_loop_head(pt, T);
+        return;
+    }
+    T.contrib = T.oq.result;
+    T.ni_ans += T.contrib;
+    T.n_start += T.delta_n;
+    if (T.n_start > 1e13) T.incr = 1.;
+    T.phase = sym_chunk_loop_head(pt, T);
+}
+
+// Final NaN policy and the dimensional prefactor (symphony.rs:144-183).
+__device__ __forceinline__ double sym_result(const SymPoint &pt, const TaskState &T, int &status_out)
+{
     status_out = T.status;
     double ans = T.ans;
     if (!rim_isfinite(ans)) {
         status_out |= ST_NONFINITE;
         return RIM_NAN;
     }
-
     const double tpe = RIM_TWO_PI * RIM_ELECTRON_CHARGE;
     const double acos_th = rim_fabs(pt.cos_th);
     if (pt.coeff == COEFF_EMISSION)
         ans = ans * ((tpe * tpe) / (RIM_SPEED_LIGHT * acos_th));
     else
         ans = ans * (-1. * (tpe * tpe) / (2. * RIM_MASS_ELECTRON * RIM_SPEED_LIGHT * acos_th));
-    RIM_HB_STAGE(310);
     return ans;
+}
+
+// The whole coefficient on one wave (no cooperation): used by the wavefront emulator and kept as
+// the readable statement of the control flow.
+template <int KIND>
+__device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const DistParams &dist, const GKLane &g,
+                                                       const IStore &inner, const IStore &outer, TaskState *park,
+                                                       QagPark *qpark, int &status_out)
+{
+    const int lane = g.lane;
+    TaskState T;
+    sym_begin(pt, T);
+    while (T.phase != PH_DONE) {
+        SymBatch B;
+        if (!sym_post(pt, g, outer, T, B)) break;
+        if (lane == 0) *park = T;        // park the uniform state in LDS while the batch runs
+        int batch_status = 0;
+        double gval = 0.;
+        unsigned long long mask = wv_ballot(B.req_active);
+        while (mask) {
+            const int k = __builtin_ffsll((long long) mask) - 1;
+            mask &= mask - 1;
+            const double n = readlane_d(B.req_n, k);
+            const int lb = wv_readlane(B.req_lobe, k);
+            const double val = sym_eval_request<KIND>(pt, dist, g, inner, qpark, n, lb, batch_status);
+            if (lane == k) gval = val;
+        }
+        wv_sync();
+        T = *park;
+        task_uniformize(T);
+        sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
+    }
+    return sym_result(pt, T, status_out);
 }
 
 }  // namespace rim
