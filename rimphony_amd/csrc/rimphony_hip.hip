@@ -11,6 +11,7 @@
 // tasks are handed out dynamically, one atomicAdd per task.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -737,6 +738,7 @@ struct rimphony_ctx {
     size_t spill_waves;
     AssistSlot *d_board;            // [board_slots] + flags behind
     size_t board_slots;
+    int no_assist;                  // RIMPHONY_NO_ASSIST=1: one wave per task to the end (A/B measurements)
     size_t norm_cap;
     // staging for the host-buffer entry point
     double *d_in;
@@ -798,6 +800,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     if (!c) return RIMPHONY_ENOMEM;
     memset(c, 0, sizeof *c);
     c->device = device;
+    { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc(&c->d_queue, 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
@@ -921,7 +924,7 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     }
     SymArgs b = a;
     b.spill = c->d_spill;
-    b.board = c->d_board;
+    b.board = c->no_assist ? nullptr : c->d_board;
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
     // every claim word starts closed (all ones); flags: not exhausted, `grid` active waves
     HIP_TRY(hipMemsetAsync(c->d_board, 0xFF, (size_t) grid * sizeof(AssistSlot), st));

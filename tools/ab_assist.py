@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""A/B: cooperative tail on/off (run twice with RIMPHONY_NO_ASSIST unset / =1)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from rimphony_amd import api, workload
+ctx = api.Context(0)
+dev = torch.device("cuda", 0)
+def run(start, n, label):
+    kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", n, start=start)
+    ds, dth, dp = torch.from_numpy(s).to(dev), torch.from_numpy(th).to(dev), [torch.from_numpy(p).to(dev) for p in params]
+    for rep in range(2):
+        out, _ = ctx.compute_batch_device(kind, ds, dth, dp, mask)
+        ms = ctx.last_symphony_ms()
+    print(label, "n", n, "kernel ms %.1f" % ms, "pts/s %.0f" % (n / ms * 1e3), flush=True)
+print("NO_ASSIST =", os.environ.get("RIMPHONY_NO_ASSIST"))
+run(222883, 1, "outlier")
+run(0, 64, "64")
+run(0, 1024, "1024")
+run(0, 4096, "4096")
+run(0, 16384, "16384")
+run(0, 65536, "65536")
+run(196608, 65536, "65536 w/ outlier")
