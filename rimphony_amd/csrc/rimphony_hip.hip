@@ -170,23 +170,26 @@ __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 //
 // Per-task cost has a heavy tail (rare points are 100-1000x the mean; the reference prints
 // "SLOW" for them).  With one wave per task, the end of a launch would be a few waves grinding
-// through such tasks while the rest of the chip idles.  Once the task queue has run dry, a wave
-// that still owns a task therefore PUBLISHES each batch of (n, lobe) requests of its state machine
-// on a slot of a board in global memory, and waves without a task claim individual requests,
-// evaluate the gamma-integral and write the value back.  Every request is a pure function of
-// (point, coefficient, n, lobe), so who evaluates it cannot change a bit of the result.
+// through such tasks while the rest of the chip idles.  Once the task queue has run dry and some
+// wave is idle, a wave that still owns a task therefore PUBLISHES each batch of (n, lobe) requests
+// of its state machine on its slot of a board in global memory, and waves without a task claim
+// individual requests, evaluate the gamma-integral and write the value back.  Every request is a
+// pure function of (point, coefficient, n, lobe), so who evaluates it cannot change a bit of the
+// result.
 //
 // Protocol (placement-independent, agent-scope release/acquire, every spin bounded):
-//   slot.claim = (seq << 32) | next      next = 0xffffffff: closed
-//   owner:  write requests -> s_waitcnt -> release fence -> s_waitcnt -> claim = (seq << 32) | 0
-//   anyone: c = load(claim); k = first request lane >= next(c) in mask; CAS(claim, c, c.next = k + 1)
-//           a successful CAS proves the batch `seq` was still open, so the request data read after
-//           the acquire fence belonged to it and stays valid until this claimer reports `done`
+//   slot.claim = (seq << 32) | (count << 8) | next        open iff next < count
+//   owner:  write the compacted requests -> s_waitcnt -> release fence -> s_waitcnt ->
+//           claim = (seq << 32) | (count << 8); advertise the slot in one of 64 hint words
+//   anyone: c = load(claim); if next(c) < count(c): CAS(claim, c, c + 1) claims request next(c).
+//           A successful CAS proves batch `seq` was still open, so the request data read after the
+//           acquire fence belonged to it and stays valid until this claimer reports `done`.
 //   result: res[k], status[k] -> s_waitcnt -> release fence -> s_waitcnt -> atomicAdd(done)
-//   owner:  poll done == popcount(mask) -> acquire fence -> read res[] -> claim = closed
+//   owner:  poll done == count -> acquire fence -> read res[] -> claim = (seq << 32) (closed)
+// Idle waves poll only the 64 hint words, with exponential back-off, and count themselves in
+// flags[2] so that owners publish only when somebody can actually help.
 struct AssistSlot {
     unsigned long long claim;
-    unsigned long long mask;
     unsigned long long point;
     unsigned done;
     int slot;
@@ -196,34 +199,44 @@ struct AssistSlot {
     int res_status[64];
 };
 
+#define BOARD_FLAG_EXHAUSTED 0
+#define BOARD_FLAG_ACTIVE 1
+#define BOARD_FLAG_IDLE 2
+#define BOARD_HINTS 16          // flags[16 .. 79]: slot index + 1 of a recently published batch
+#define BOARD_FLAG_WORDS 80
+
 __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v)
 {
     return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (v >> 32)) << 32) |
            (unsigned) __builtin_amdgcn_readfirstlane((int) (v & 0xffffffffull));
 }
 
+__device__ __forceinline__ bool claim_open(unsigned long long c) { return (unsigned) (c & 0xff) < (unsigned) ((c >> 8) & 0xff); }
+
 // Claim the next unevaluated request of batch `seq` on `slot`; -1 if there is none (or the batch is over).
-__device__ __forceinline__ int assist_claim(AssistSlot *slot, unsigned seq, unsigned long long mask, int lane)
+__device__ __forceinline__ int assist_claim(AssistSlot *slot, unsigned seq, int lane)
 {
     int k = -1;
     if (lane == 0) {
-        for (int tries = 0; tries < 4096; tries++) {
+        for (int tries = 0; tries < 64; tries++) {
             const unsigned long long c = __hip_atomic_load(&slot->claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned nxt = (unsigned) (c & 0xffffffffull);
-            if ((unsigned) (c >> 32) != seq || nxt >= 64u) break;
-            const unsigned long long rest = mask >> nxt;
-            if (rest == 0) break;
-            const int kb = (int) nxt + __builtin_ffsll((long long) rest) - 1;
+            if ((unsigned) (c >> 32) != seq || !claim_open(c)) break;
             unsigned long long expect = c;
-            const unsigned long long want = ((unsigned long long) seq << 32) | (unsigned) (kb + 1);
-            if (__hip_atomic_compare_exchange_strong(&slot->claim, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) { k = kb; break; }
+            if (__hip_atomic_compare_exchange_strong(&slot->claim, &expect, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) { k = (int) (c & 0xff); break; }
         }
     }
     return __builtin_amdgcn_readfirstlane(k);
 }
 
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// lane index of the k-th set bit of mask (k < popcount(mask))
+__device__ __forceinline__ int kth_set_bit(unsigned long long mask, int k)
+{
+    for (int i = 0; i < k; i++) mask &= mask - 1;
+    return __builtin_ffsll((long long) mask) - 1;
+}
 
 template <int KIND>
 __device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slot, SymPoint &pt, DistParams &d, double &norm)
@@ -260,10 +273,14 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
     AssistSlot *const my = a.board + blockIdx.x;
-    unsigned *const flag_exhausted = a.board_flags;
-    unsigned *const flag_active = a.board_flags + 1;
+    unsigned *const flag_exhausted = a.board_flags + BOARD_FLAG_EXHAUSTED;
+    unsigned *const flag_active = a.board_flags + BOARD_FLAG_ACTIVE;
+    unsigned *const flag_idle = a.board_flags + BOARD_FLAG_IDLE;
+    unsigned *const hints = a.board_flags + BOARD_HINTS;
     const unsigned nboard = gridDim.x;
     unsigned seq = 0;                      // sequence number of this wave's published batches
+    bool counted_idle = false;             // this wave is currently counted in flags[IDLE]
+    int backoff = 1;
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     SymPoint pt;                           // context of the requests being evaluated (own task or a helped one)
@@ -341,18 +358,24 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             if (finished) { have_task = false; continue; }
             mask = wv_ballot(B.req_active);
 
-            // publish the batch when other waves have nothing left to do
-            unsigned ex = 0;
-            if (lane == 0 && a.board) ex = __hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ex = (unsigned) __builtin_amdgcn_readfirstlane((int) ex);
-            shared = ex != 0 && __builtin_popcountll(mask) >= 2;
+            // publish the batch when some wave is idle
+            unsigned idle = 0;
+            if (lane == 0 && a.board) {
+                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    idle = __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
+            const int cnt = __builtin_popcountll(mask);
+            shared = idle != 0 && cnt >= 2;
             if (shared) {
                 seq += 1;
                 src_seq = seq;
-                my->req_n[lane] = B.req_n;
-                my->req_lobe[lane] = B.req_lobe;
+                if (B.req_active) {
+                    const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    my->req_n[rank] = B.req_n;
+                    my->req_lobe[rank] = B.req_lobe;
+                }
                 if (lane == 0) {
-                    my->mask = mask;
                     my->point = (unsigned long long) own_i;
                     my->slot = own_slot;
                     my->done = 0;
@@ -362,41 +385,47 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 if (lane == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     drain_vmem();
-                    __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) cnt << 8),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&hints[(blockIdx.x + seq) & 63u], (unsigned) blockIdx.x + 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         } else {
-            // ---------- helper: find a published batch ----------
-            int found = -1;
-            unsigned long long cw = 0;
-            for (unsigned base = 0; base < nboard && found < 0; base += 64) {
-                const unsigned j = (scan_rot + base + (unsigned) lane) % nboard;
-                unsigned long long c = 0xffffffffffffffffull;
-                if (base + (unsigned) lane < nboard)
-                    c = __hip_atomic_load(&a.board[j].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool open = (unsigned) (c & 0xffffffffull) < 64u;
-                const unsigned long long om = wv_ballot(open);
-                if (om) {
-                    const int src_lane = __builtin_ffsll((long long) om) - 1;
-                    found = (int) ((scan_rot + base + (unsigned) src_lane) % nboard);
-                    cw = bcast_u64(__shfl(c, src_lane));
+            // ---------- helper: find a published batch through the hint words ----------
+            unsigned hslot = 0;
+            unsigned long long c = 0;
+            {
+                const unsigned h = __hip_atomic_load(&hints[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h != 0 && h <= nboard) {
+                    c = __hip_atomic_load(&a.board[h - 1].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (claim_open(c)) hslot = h;
                 }
             }
-            if (found < 0) {
+            const unsigned long long om = wv_ballot(hslot != 0);
+            if (om == 0) {
+                if (!counted_idle) {
+                    if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    counted_idle = true;
+                }
                 unsigned act = 1;
                 if (lane == 0) act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
                 if (act == 0) break;       // every task is finished
-                __builtin_amdgcn_s_sleep(64);
-                scan_rot += 64;
+                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
+                if (backoff < 16) backoff *= 2;
                 continue;
             }
+            // pick one of the open hints, rotating so that helpers spread over the open batches
+            const unsigned long long rot = (om >> (scan_rot & 63u)) | (om << ((64u - (scan_rot & 63u)) & 63u));
+            const int pick = (int) (((unsigned) (__builtin_ffsll((long long) rot) - 1) + (scan_rot & 63u)) & 63u);
+            const unsigned found = (unsigned) __builtin_amdgcn_readlane((int) hslot, pick) - 1u;
+            const unsigned long long cw = bcast_u64(__shfl(c, pick));
             src = a.board + found;
             src_seq = (unsigned) (cw >> 32);
             if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             drain_vmem();
             __syncthreads();
-            mask = bcast_u64(src->mask);
             shared = true;
             // context of the helped task is loaded after the first successful claim (below)
         }
@@ -409,7 +438,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         for (;;) {
             int k;
             if (shared) {
-                k = assist_claim(src, src_seq, mask, lane);
+                k = assist_claim(src, src_seq, lane);      // ordinal of the request within the batch
             } else {
                 k = local_mask ? __builtin_ffsll((long long) local_mask) - 1 : -1;
                 local_mask &= local_mask - 1;
@@ -421,15 +450,21 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 if (!ctx_loaded) {
                     double norm;
                     const size_t hi = (size_t) bcast_u64(src->point);
-                    const int hslot = __builtin_amdgcn_readfirstlane(src->slot);
-                    load_context<KIND>(a, hi, hslot, pt, d, norm);
+                    const int hs = __builtin_amdgcn_readfirstlane(src->slot);
+                    load_context<KIND>(a, hi, hs, pt, d, norm);
                     ctx_loaded = true;
+                    if (counted_idle) {
+                        if (lane == 0) __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        counted_idle = false;
+                    }
+                    backoff = 1;
                 }
                 n = uni(src->req_n[k]);
                 lb = __builtin_amdgcn_readfirstlane(src->req_lobe[k]);
             } else {
-                n = readlane_d(B.req_n, k);
-                lb = wv_readlane(B.req_lobe, k);
+                const int kl = shared ? kth_set_bit(mask, k) : k;     // lane that posted the request
+                n = readlane_d(B.req_n, kl);
+                lb = wv_readlane(B.req_lobe, kl);
             }
             if (lane == 0 && s_qpark.hb) {
                 hb_store(s_qpark.hb + 8, (unsigned long long) k);
@@ -451,11 +486,12 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 batch_status |= st;
             }
         }
-        if (helper) { scan_rot += 1; continue; }
+        if (helper) { scan_rot += 7; continue; }
 
         // ---------- owner: collect a shared batch, then the continuation ----------
         if (shared) {
             const unsigned want = (unsigned) __builtin_popcountll(mask);
+            const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
             bool complete = false;
             const unsigned long long t0 = wall_clock64();
             for (;;) {
@@ -470,13 +506,12 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             drain_vmem();
             __syncthreads();
             int stl = 0;
-            if ((mask >> lane) & 1ull) { gval = my->res[lane]; stl = my->res_status[lane]; }
+            if ((mask >> lane) & 1ull) { gval = my->res[rank]; stl = my->res_status[rank]; }
             if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
             if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
             if (!complete) { batch_status |= ST_CHUNK_CAP; gval = RIM_NAN; }
             if (lane == 0)
-                __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | 0xffffffffull, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         {
@@ -499,7 +534,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 
 __global__ void board_init_kernel(unsigned *flags, unsigned active)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { flags[0] = 0; flags[1] = active; }
+    const unsigned i = threadIdx.x;
+    if (blockIdx.x == 0 && i < BOARD_FLAG_WORDS) flags[i] = (i == BOARD_FLAG_ACTIVE) ? active : 0u;
 }
 
 // ------------------------------------------------------------------------------
@@ -919,16 +955,17 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
         if (c->d_board) (void) hipFree(c->d_board);
         c->d_board = nullptr;
         c->board_slots = 0;
-        if (hipMalloc(&c->d_board, (size_t) grid * sizeof(AssistSlot) + 64) != hipSuccess) return RIMPHONY_ENOMEM;
+        if (hipMalloc(&c->d_board, (size_t) grid * sizeof(AssistSlot) + BOARD_FLAG_WORDS * sizeof(unsigned)) != hipSuccess)
+            return RIMPHONY_ENOMEM;
         c->board_slots = grid;
     }
     SymArgs b = a;
     b.spill = c->d_spill;
     b.board = c->no_assist ? nullptr : c->d_board;
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
-    // every claim word starts closed (all ones); flags: not exhausted, `grid` active waves
-    HIP_TRY(hipMemsetAsync(c->d_board, 0xFF, (size_t) grid * sizeof(AssistSlot), st));
-    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(64), 0, st, b.board_flags, grid);
+    // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
+    HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
+    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), 0, st, b.board_flags, grid);
     HIP_TRY(hipEventRecord(c->ev_start, st));
     hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
     HIP_TRY(hipGetLastError());
