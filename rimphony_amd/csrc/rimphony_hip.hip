@@ -179,13 +179,13 @@ __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 //
 // Protocol (placement-independent, agent-scope release/acquire, every spin bounded):
 //   slot.claim = (seq << 32) | (count << 8) | next        open iff next < count
-//   owner:  write the compacted requests -> s_waitcnt -> release fence -> s_waitcnt ->
+//   owner:  write the compacted requests (sc1 stores) -> s_waitcnt vmcnt(0) ->
 //           claim = (seq << 32) | (count << 8); advertise the slot in one of 64 hint words
 //   anyone: c = load(claim); if next(c) < count(c): CAS(claim, c, c + 1) claims request next(c).
-//           A successful CAS proves batch `seq` was still open, so the request data read after the
-//           acquire fence belonged to it and stays valid until this claimer reports `done`.
-//   result: res[k], status[k] -> s_waitcnt -> release fence -> s_waitcnt -> atomicAdd(done)
-//   owner:  poll done == count -> acquire fence -> read res[] -> claim = (seq << 32) (closed)
+//           A successful CAS proves batch `seq` was still open, so the request data (read with sc1
+//           loads) belonged to it and stays valid until this claimer reports `done`.
+//   result: res[k], status[k] (sc1 stores) -> s_waitcnt vmcnt(0) -> atomicAdd(done)
+//   owner:  poll done == count -> read res[] (sc1 loads) -> claim = (seq << 32) (closed)
 // Idle waves poll only the 64 hint words, with exponential back-off, and count themselves in
 // flags[2] so that owners publish only when somebody can actually help.
 struct AssistSlot {
@@ -193,11 +193,26 @@ struct AssistSlot {
     unsigned long long point;
     unsigned done;
     int slot;
-    double req_n[64];
-    double res[64];
+    unsigned long long req_n[64];     // bit patterns of doubles: every access is an agent-scope atomic
+    unsigned long long res[64];
     int req_lobe[64];
     int res_status[64];
 };
+
+// Board payload accessors: relaxed agent-scope atomics = sc1 (write-through / L1-bypassing) stores
+// and loads.  Thousands of waves use the board at the same time at the end of a launch; agent-scope
+// release/acquire FENCES there (an L2 write-back + L1 invalidate each) serialise on the XCD's L2 and
+// cost more than the work being shared, so the hand-off uses write-through granules instead:
+// sc1 stores -> s_waitcnt vmcnt(0) -> counter/flag atomic on the producer, sc1 loads after the
+// poll on the consumer (MI355X_MICROARCH.md, "Valid forms").
+__device__ __forceinline__ void bput(unsigned long long *p, unsigned long long v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bput(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bput(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long bget(const unsigned long long *p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int bget(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned bget(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define BOARD_FLAG_EXHAUSTED 0
 #define BOARD_FLAG_ACTIVE 1
@@ -372,19 +387,17 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 src_seq = seq;
                 if (B.req_active) {
                     const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                    my->req_n[rank] = B.req_n;
-                    my->req_lobe[rank] = B.req_lobe;
+                    bput(&my->req_n[rank], rim_bits(B.req_n));
+                    bput(&my->req_lobe[rank], B.req_lobe);
                 }
                 if (lane == 0) {
-                    my->point = (unsigned long long) own_i;
-                    my->slot = own_slot;
-                    my->done = 0;
+                    bput(&my->point, (unsigned long long) own_i);
+                    bput(&my->slot, own_slot);
+                    bput(&my->done, 0u);
                 }
                 drain_vmem();
                 __syncthreads();
                 if (lane == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    drain_vmem();
                     __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) cnt << 8),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&hints[(blockIdx.x + seq) & 63u], (unsigned) blockIdx.x + 1u, __ATOMIC_RELAXED,
@@ -423,9 +436,6 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             const unsigned long long cw = bcast_u64(__shfl(c, pick));
             src = a.board + found;
             src_seq = (unsigned) (cw >> 32);
-            if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            drain_vmem();
-            __syncthreads();
             shared = true;
             // context of the helped task is loaded after the first successful claim (below)
         }
@@ -449,8 +459,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             if (helper) {
                 if (!ctx_loaded) {
                     double norm;
-                    const size_t hi = (size_t) bcast_u64(src->point);
-                    const int hs = __builtin_amdgcn_readfirstlane(src->slot);
+                    const size_t hi = (size_t) bcast_u64(bget(&src->point));
+                    const int hs = __builtin_amdgcn_readfirstlane(bget(&src->slot));
                     load_context<KIND>(a, hi, hs, pt, d, norm);
                     ctx_loaded = true;
                     if (counted_idle) {
@@ -459,8 +469,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                     }
                     backoff = 1;
                 }
-                n = uni(src->req_n[k]);
-                lb = __builtin_amdgcn_readfirstlane(src->req_lobe[k]);
+                n = uni(rim_frombits(bget(&src->req_n[k])));
+                lb = __builtin_amdgcn_readfirstlane(bget(&src->req_lobe[k]));
             } else {
                 const int kl = shared ? kth_set_bit(mask, k) : k;     // lane that posted the request
                 n = readlane_d(B.req_n, kl);
@@ -474,10 +484,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, st);
             if (shared) {
                 if (lane == 0) {
-                    src->res[k] = val;
-                    src->res_status[k] = st;
-                    drain_vmem();
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    bput(&src->res[k], rim_bits(val));
+                    bput(&src->res_status[k], st);
                     drain_vmem();
                     __hip_atomic_fetch_add(&src->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -502,11 +510,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
                 __builtin_amdgcn_s_sleep(32);
             }
-            if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            drain_vmem();
-            __syncthreads();
             int stl = 0;
-            if ((mask >> lane) & 1ull) { gval = my->res[rank]; stl = my->res_status[rank]; }
+            if ((mask >> lane) & 1ull) { gval = rim_frombits(bget(&my->res[rank])); stl = bget(&my->res_status[rank]); }
             if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
             if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
             if (!complete) { batch_status |= ST_CHUNK_CAP; gval = RIM_NAN; }
