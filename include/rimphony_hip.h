@@ -121,6 +121,13 @@ int rimphony_last_symphony_ms(rimphony_ctx *ctx, float *ms);
  * are addressed as task | (1 << 62). */
 int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_words);
 
+/* Diagnostics: the 16 raw device counter words of the most recent batch call: [0] task head,
+ * [1..3] Symphony samples / passes / inner QAGs, [4] Faraday task head, [5..7] Faraday work,
+ * [8] batches published on the assist board, [9] requests evaluated by helper waves,
+ * [10] requests of published batches evaluated by their owner, [11] owner wait (100 MHz ticks),
+ * [12] helper polls, [13] helper visits that found every request already claimed. */
+int rimphony_debug_counters(rimphony_ctx *ctx, uint64_t out[16]);
+
 /* The batched compute(): N x (full_calculation + compute_all_dimensionless).
  *   d_s, d_theta   [n]                device
  *   d_params       host array of rimphony_dist_nparams(kind) DEVICE pointers, each [n]

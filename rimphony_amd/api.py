@@ -137,6 +137,11 @@ class Context:
         capi.check(self.lib.rimphony_last_symphony_ms(self.handle, ctypes.byref(ms)), "rimphony_last_symphony_ms")
         return float(ms.value)
 
+    def debug_counters(self):
+        arr = (ctypes.c_uint64 * 16)()
+        capi.check(self.lib.rimphony_debug_counters(self.handle, arr), "rimphony_debug_counters")
+        return [int(v) for v in arr]
+
     def heartbeat(self, task=0):
         """Diagnostics: returns a ctypes pointer to 16 host-mapped uint64 words (see rimphony_hip.h)."""
         p = ctypes.POINTER(ctypes.c_uint64)()

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     unsigned seq = 0;                      // sequence number of this wave's published batches
     bool counted_idle = false;             // this wave is currently counted in flags[IDLE]
     int backoff = 1;
+    // diagnostics of the cooperative tail (queue words 8..13)
+    unsigned long long n_shared_batches = 0, n_helper_reqs = 0, n_owner_shared_reqs = 0, wait_ticks = 0, n_polls = 0,
+                       n_empty_claims = 0;
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     SymPoint pt;                           // context of the requests being evaluated (own task or a helped one)
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             if (shared) {
                 seq += 1;
                 src_seq = seq;
+                n_shared_batches += 1;
                 if (B.req_active) {
                     const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                     bput(&my->req_n[rank], rim_bits(B.req_n));
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 }
             }
             const unsigned long long om = wv_ballot(hslot != 0);
+            n_polls += 1;
             if (om == 0) {
                 if (!counted_idle) {
                     if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         double gval = 0.;
         bool ctx_loaded = !helper;
         unsigned long long local_mask = mask;
+        int got = 0;
         for (;;) {
             int k;
             if (shared) {
@@ -454,6 +460,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 local_mask &= local_mask - 1;
             }
             if (k < 0) break;
+            got += 1;
+            if (shared) { if (helper) n_helper_reqs += 1; else n_owner_shared_reqs += 1; }
             double n;
             int lb;
             if (helper) {
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 batch_status |= st;
             }
         }
-        if (helper) { scan_rot += 7; continue; }
+        if (helper) { if (got == 0) n_empty_claims += 1; scan_rot += 7; continue; }
 
         // ---------- owner: collect a shared batch, then the continuation ----------
         if (shared) {
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 unsigned dn = 0;
                 if (lane == 0) dn = __hip_atomic_load(&my->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dn = (unsigned) __builtin_amdgcn_readfirstlane((int) dn);
-                if (dn >= want) { complete = true; break; }
+                if (dn >= want) { complete = true; wait_ticks += wall_clock64() - t0; break; }
                 if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
                 __builtin_amdgcn_s_sleep(32);
             }
@@ -534,6 +542,12 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         atomicAdd(a.queue + 1, s_qpark.ctr.samples);
         atomicAdd(a.queue + 2, s_qpark.ctr.steps);
         atomicAdd(a.queue + 3, s_qpark.ctr.inner_qags);
+        atomicAdd(a.queue + 8, n_shared_batches);
+        atomicAdd(a.queue + 9, n_helper_reqs);
+        atomicAdd(a.queue + 10, n_owner_shared_reqs);
+        atomicAdd(a.queue + 11, wait_ticks);
+        atomicAdd(a.queue + 12, n_polls);
+        atomicAdd(a.queue + 13, n_empty_claims);
     }
 }
 
@@ -843,7 +857,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     c->device = device;
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&c->d_queue, 8 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
+    if (hipMalloc(&c->d_queue, 16 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         (void) hipFree(c->d_queue);
         delete c;
@@ -1056,7 +1070,7 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         if (coeff_mask & (1u << k)) { fa.slot[fa.nslots++] = k; computed |= 1u << k; }
     for (int k = fa.nslots; k < 8; k++) fa.slot[k] = 0;
 
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 16 * sizeof(unsigned long long), st));
     {
         const size_t total = n * 8;
         hipLaunchKernelGGL(fill_unselected_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
@@ -1098,6 +1112,14 @@ extern "C" int rimphony_debug_heartbeat(rimphony_ctx *c, uint64_t task, uint64_t
     }
     c->hb_task = task;
     *host_words = (uint64_t *) c->hb_host;
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[16])
+{
+    if (!c || !out) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(out, c->d_queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RIMPHONY_OK;
 }
 

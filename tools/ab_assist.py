@@ -13,12 +13,13 @@ def run(start, n, label):
     for rep in range(2):
         out, _ = ctx.compute_batch_device(kind, ds, dth, dp, mask)
         ms = ctx.last_symphony_ms()
-    print(label, "n", n, "kernel ms %.1f" % ms, "pts/s %.0f" % (n / ms * 1e3), flush=True)
+    c = ctx.debug_counters()
+    print(label, "n", n, "kernel ms %.1f" % ms, "pts/s %.0f" % (n / ms * 1e3), "| inner_qags", c[3], "shared_batches", c[8],
+          "helper_reqs", c[9], "owner_shared_reqs", c[10], "owner_wait_ms_total %.1f" % (c[11] / 1e5), "polls", c[12],
+          "empty_visits", c[13], flush=True)
 print("NO_ASSIST =", os.environ.get("RIMPHONY_NO_ASSIST"))
 run(222883, 1, "outlier")
 run(0, 64, "64")
 run(0, 1024, "1024")
 run(0, 4096, "4096")
 run(0, 16384, "16384")
-run(0, 65536, "65536")
-run(196608, 65536, "65536 w/ outlier")
