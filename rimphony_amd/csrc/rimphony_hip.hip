@@ -327,7 +327,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                     if (lane == 0) {
                         __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (a.board) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    counted_idle = true;      // flags[IDLE] = helper waves that are not evaluating a request
                     if (!a.board) break;     // cooperation disabled
                     continue;
                 }
@@ -422,10 +424,6 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             const unsigned long long om = wv_ballot(hslot != 0);
             n_polls += 1;
             if (om == 0) {
-                if (!counted_idle) {
-                    if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    counted_idle = true;
-                }
                 unsigned act = 1;
                 if (lane == 0) act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
@@ -502,7 +500,19 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 batch_status |= st;
             }
         }
-        if (helper) { if (got == 0) n_empty_claims += 1; scan_rot += 7; continue; }
+        if (helper) {
+            scan_rot += 7;
+            if (got == 0) {
+                // every request of that batch was already taken: back off before looking again
+                n_empty_claims += 1;
+                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
+                if (backoff < 16) backoff *= 2;
+            } else {
+                if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counted_idle = true;
+            }
+            continue;
+        }
 
         // ---------- owner: collect a shared batch, then the continuation ----------
         if (shared) {
