@@ -226,6 +226,15 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v)
            (unsigned) __builtin_amdgcn_readfirstlane((int) (v & 0xffffffffull));
 }
 
+// Number of hint words in use (power of two <= 64): about one per wave that still owns a task, so
+// that each published batch is seen by (idle waves / owners) helpers.
+__device__ __forceinline__ unsigned hint_span(unsigned active)
+{
+    unsigned h = 1;
+    while (h < 64u && h * 2u <= active) h *= 2u;
+    return h;
+}
+
 __device__ __forceinline__ bool claim_open(unsigned long long c) { return (unsigned) (c & 0xff) < (unsigned) ((c >> 8) & 0xff); }
 
 // Claim the next unevaluated request of batch `seq` on `slot`; -1 if there is none (or the batch is over).
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     int backoff = 1;
     // diagnostics of the cooperative tail (queue words 8..13)
     unsigned long long n_shared_batches = 0, n_helper_reqs = 0, n_owner_shared_reqs = 0, wait_ticks = 0, n_polls = 0,
-                       n_empty_claims = 0;
+                       n_empty_claims = 0, eval_ticks = 0, max_wait = 0;
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     SymPoint pt;                           // context of the requests being evaluated (own task or a helped one)
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     bool have_task = false, helper = false;
     unsigned scan_rot = blockIdx.x;
 
+    __builtin_amdgcn_s_setprio(3);
     for (;;) {
         SymBatch B;
         B.req_n = 0.; B.req_lobe = 0; B.req_active = false; B.n_req = 0; B.phase = PH_DONE;
@@ -330,6 +340,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                         if (a.board) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     counted_idle = true;      // flags[IDLE] = helper waves that are not evaluating a request
+                    // Helpers run below the issue priority of waves that own a task: an owner's serial
+                    // bookkeeping between batches is the critical path of the tail.
+                    __builtin_amdgcn_s_setprio(0);
                     if (!a.board) break;     // cooperation disabled
                     continue;
                 }
@@ -379,12 +392,15 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             mask = wv_ballot(B.req_active);
 
             // publish the batch when some wave is idle
-            unsigned idle = 0;
+            unsigned idle = 0, act = 1;
             if (lane == 0 && a.board) {
-                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     idle = __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
+            act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
             const int cnt = __builtin_popcountll(mask);
             shared = idle != 0 && cnt >= 2;
             if (shared) {
@@ -406,38 +422,38 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 if (lane == 0) {
                     __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) cnt << 8),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&hints[(blockIdx.x + seq) & 63u], (unsigned) blockIdx.x + 1u, __ATOMIC_RELAXED,
+                    __hip_atomic_store(&hints[(blockIdx.x + seq) & (hint_span(act) - 1u)], (unsigned) blockIdx.x + 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         } else {
             // ---------- helper: find a published batch through the hint words ----------
-            unsigned hslot = 0;
+            // One lane looks at ONE hint word per poll (two sc1 loads): thousands of waves poll at the
+            // end of a launch, and wave-wide polling of all hints measurably slows the waves that compute.
+            unsigned h = 0, act = 1;
             unsigned long long c = 0;
-            {
-                const unsigned h = __hip_atomic_load(&hints[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h = __hip_atomic_load(&hints[scan_rot & (hint_span(act) - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (h != 0 && h <= nboard) {
                     c = __hip_atomic_load(&a.board[h - 1].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (claim_open(c)) hslot = h;
+                    if (!claim_open(c)) h = 0;
+                } else {
+                    h = 0;
                 }
             }
-            const unsigned long long om = wv_ballot(hslot != 0);
+            h = (unsigned) __builtin_amdgcn_readfirstlane((int) h);
+            act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
             n_polls += 1;
-            if (om == 0) {
-                unsigned act = 1;
-                if (lane == 0) act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
+            scan_rot += 1;
+            if (h == 0) {
                 if (act == 0) break;       // every task is finished
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
                 if (backoff < 16) backoff *= 2;
                 continue;
             }
-            // pick one of the open hints, rotating so that helpers spread over the open batches
-            const unsigned long long rot = (om >> (scan_rot & 63u)) | (om << ((64u - (scan_rot & 63u)) & 63u));
-            const int pick = (int) (((unsigned) (__builtin_ffsll((long long) rot) - 1) + (scan_rot & 63u)) & 63u);
-            const unsigned found = (unsigned) __builtin_amdgcn_readlane((int) hslot, pick) - 1u;
-            const unsigned long long cw = bcast_u64(__shfl(c, pick));
-            src = a.board + found;
+            const unsigned long long cw = bcast_u64(c);
+            src = a.board + (h - 1u);
             src_seq = (unsigned) (cw >> 32);
             shared = true;
             // context of the helped task is loaded after the first successful claim (below)
@@ -487,7 +503,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 hb_store(s_qpark.hb + 9, rim_bits(n));
             }
             int st = 0;
+            const unsigned long long e0 = wall_clock64();
             const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, st);
+            eval_ticks += wall_clock64() - e0;
             if (shared) {
                 if (lane == 0) {
                     bput(&src->res[k], rim_bits(val));
@@ -501,7 +519,6 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             }
         }
         if (helper) {
-            scan_rot += 7;
             if (got == 0) {
                 // every request of that batch was already taken: back off before looking again
                 n_empty_claims += 1;
@@ -524,7 +541,13 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 unsigned dn = 0;
                 if (lane == 0) dn = __hip_atomic_load(&my->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dn = (unsigned) __builtin_amdgcn_readfirstlane((int) dn);
-                if (dn >= want) { complete = true; wait_ticks += wall_clock64() - t0; break; }
+                if (dn >= want) {
+                    complete = true;
+                    const unsigned long long w = wall_clock64() - t0;
+                    wait_ticks += w;
+                    if (w > max_wait) max_wait = w;
+                    break;
+                }
                 if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
                 __builtin_amdgcn_s_sleep(32);
             }
@@ -558,6 +581,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         atomicAdd(a.queue + 11, wait_ticks);
         atomicAdd(a.queue + 12, n_polls);
         atomicAdd(a.queue + 13, n_empty_claims);
+        atomicAdd(a.queue + 14, eval_ticks);
+        atomicMax(a.queue + 15, max_wait);
     }
 }
 

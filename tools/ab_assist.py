@@ -16,10 +16,13 @@ def run(start, n, label):
     c = ctx.debug_counters()
     print(label, "n", n, "kernel ms %.1f" % ms, "pts/s %.0f" % (n / ms * 1e3), "| inner_qags", c[3], "shared_batches", c[8],
           "helper_reqs", c[9], "owner_shared_reqs", c[10], "owner_wait_ms_total %.1f" % (c[11] / 1e5), "polls", c[12],
-          "empty_visits", c[13], flush=True)
+          "empty_visits", c[13], "eval_us_per_req %.1f" % (c[14] / 100. / max(c[3], 1)), "max_wait_ms %.2f" % (c[15] / 1e5),
+          flush=True)
 print("NO_ASSIST =", os.environ.get("RIMPHONY_NO_ASSIST"))
 run(222883, 1, "outlier")
 run(0, 64, "64")
 run(0, 1024, "1024")
-run(0, 4096, "4096")
-run(0, 16384, "16384")
+if os.environ.get("AB_BIG"):
+    run(0, 4096, "4096")
+    run(0, 16384, "16384")
+    run(0, 65536, "65536")
