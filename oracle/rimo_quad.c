@@ -25,7 +25,7 @@ static double rescale_error(double err, const double result_abs, const double re
 {
     err = m_fabs(err);
     if (result_asc != 0 && err != 0) {
-        double scale = m_pow((200 * err / result_asc), 1.5);
+        double scale = m_pow15(200 * err / result_asc);
         if (scale < 1)
             err = result_asc * scale;
         else

@@ -28,6 +28,17 @@
 #define RIM_FN static inline
 #endif
 
+/* Region timers of the diagnostic build (-DRIM_PROF, tools/region_profile.py); no-ops otherwise. */
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_rim_prof[];
+#define RIM_PROF_T(t) const unsigned long long t = __builtin_readcyclecounter()
+#define RIM_PROF_ADD(idx, t) do { if ((threadIdx.x & 63) == 0) \
+    g_rim_prof[(size_t) blockIdx.x * 16 + (idx)] += __builtin_readcyclecounter() - t; } while (0)
+#else
+#define RIM_PROF_T(t)
+#define RIM_PROF_ADD(idx, t)
+#endif
+
 #define RIM_NAN (__builtin_nan(""))
 #define RIM_INF (__builtin_inf())
 #define RIM_PI 3.14159265358979323846
@@ -228,6 +239,9 @@ RIM_FN double rim_pow(double x, double y)
     if (ph < -800.0) return sign * 0.0;
     return sign * rim_exp_dd(ph, pl);
 }
+
+/* x^1.5 for x >= 0 as x * sqrt(x) (two roundings; used by the GK error rescaling, qk.c) */
+RIM_FN double rim_pow15(double x) { return x * rim_sqrt(x); }
 
 /* ---- lgamma (positive arguments only) --------------------------------- */
 

@@ -63,11 +63,27 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
     return f_factor * rim_exp(f_exp);
 }
 
+// 10^t to single precision (relative error ~1e-6; only ever used behind a 1e-3 guard band, so the
+// host and device versions need not agree bit for bit).
+RIM_DEV double guard_pow10(double t)
+{
+    const float a = (float) (t * 3.321928094887362);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (double) __builtin_amdgcn_exp2f(a);
+#else
+    return (double) __builtin_exp2f(a);
+#endif
+}
+
 // Order-only quantities of pkgw_bessel_j / BesselJ_Meissel_First.
 struct LeungOrder {
     double n;
     double thr_lo, thr_hi;      // -0.6666666 log10 n + {0.174857, 0.295966}   (x < n side)
     double thr_plus_lo;         // -0.6666666 log10 n + 0.151550               (x > n side)
+    // The same three thresholds in the linear domain (10^thr, from a single-precision exp2) with a
+    // relative guard band of 1e-3 pushed outwards: a ratio outside [r_*_dn, r_*_up] is on the same
+    // side of the threshold as its log10 (which is what bessel.c compares) and needs no logarithm.
+    double r_lo_dn, r_hi_up, rp_dn, rp_up;
     double ninv, np1;
     double vsum2;               // -(ninv (420 + (-14 + (-4 + 3 t2) t2) t2)) / 5040
     double lgam;                // lgamma(n)
@@ -83,6 +99,10 @@ RIM_DEV LeungOrder leung_order(double n)
     o.thr_lo = -0.6666666 * logn + 0.174857;
     o.thr_hi = -0.6666666 * logn + 0.295966;
     o.thr_plus_lo = -0.6666666 * logn + 0.151550;
+    o.r_lo_dn = guard_pow10(o.thr_lo) * (1. - 1e-3);
+    o.r_hi_up = guard_pow10(o.thr_hi) * (1. + 1e-3);
+    o.rp_dn = guard_pow10(o.thr_plus_lo) * (1. - 1e-3);
+    o.rp_up = guard_pow10(o.thr_plus_lo) * (1. + 1e-3);
     o.ninv = 1. / n;
     o.np1 = n + 1.;
     const double t2 = o.ninv * o.ninv;
@@ -259,25 +279,41 @@ RIM_DEV double leung_j(const LeungOrder &o, double x)
     if (!(x >= 0)) return RIM_NAN;
     bool need_debye, need_meissel, blend = false, unsupported = false;
     double pos = 0.;
+    RIM_PROF_T(t_sel);
     if (x == n) {
         need_debye = true; need_meissel = false;
     } else if (x < n) {
-        const double eta = rim_log10((n - x) / n);
-        if (eta < o.thr_lo) { need_debye = true; need_meissel = false; }
-        else if (eta > o.thr_hi) { need_debye = false; need_meissel = true; }
+        const double r = (n - x) / n;
+        if (r < o.r_lo_dn) { need_debye = true; need_meissel = false; }
+        else if (r > o.r_hi_up) { need_debye = false; need_meissel = true; }
         else {
-            need_debye = true; need_meissel = true; blend = true;
-            pos = (eta - o.thr_lo) / (0.295966 - 0.174857);
+            const double eta = rim_log10(r);
+            if (eta < o.thr_lo) { need_debye = true; need_meissel = false; }
+            else if (eta > o.thr_hi) { need_debye = false; need_meissel = true; }
+            else {
+                need_debye = true; need_meissel = true; blend = true;
+                pos = (eta - o.thr_lo) / (0.295966 - 0.174857);
+            }
         }
     } else {
-        const double eta = rim_log10((x - n) / x);
+        const double r = (x - n) / x;
         need_meissel = false;
-        if (eta < o.thr_plus_lo) need_debye = true;
-        else { need_debye = false; unsupported = true; }   // Meissel "second" region: off the hot path
+        if (r < o.rp_dn) need_debye = true;
+        else if (r > o.rp_up) { need_debye = false; unsupported = true; }   // Meissel "second" region: off the hot path
+        else {
+            const double eta = rim_log10(r);
+            if (eta < o.thr_plus_lo) need_debye = true;
+            else { need_debye = false; unsupported = true; }
+        }
     }
     double debye = 0., meissel1 = 0.;
+    RIM_PROF_ADD(3, t_sel);
+    RIM_PROF_T(t_deb);
     if (need_debye) debye = debye_eps(n, x);
+    RIM_PROF_ADD(4, t_deb);
+    RIM_PROF_T(t_mei);
     if (need_meissel) meissel1 = meissel_first(o, x);
+    RIM_PROF_ADD(5, t_mei);
     if (unsupported) return RIM_NAN;
     if (blend) return debye * (1 - pos) + meissel1 * pos;
     return need_debye ? debye : meissel1;

@@ -145,6 +145,10 @@ RIM_DEV LeungOrder select_order(bool second, const LeungOrder &a, const LeungOrd
     o.thr_lo = second ? b.thr_lo : a.thr_lo;
     o.thr_hi = second ? b.thr_hi : a.thr_hi;
     o.thr_plus_lo = second ? b.thr_plus_lo : a.thr_plus_lo;
+    o.r_lo_dn = second ? b.r_lo_dn : a.r_lo_dn;
+    o.r_hi_up = second ? b.r_hi_up : a.r_hi_up;
+    o.rp_dn = second ? b.rp_dn : a.rp_dn;
+    o.rp_up = second ? b.rp_up : a.rp_up;
     o.ninv = second ? b.ninv : a.ninv;
     o.np1 = second ? b.np1 : a.np1;
     o.vsum2 = second ? b.vsum2 : a.vsum2;
@@ -180,7 +184,9 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
             jv0 = RIM_NAN; jv1 = RIM_NAN;
         } else {
             double a, b;
+            RIM_PROF_T(t_mil);
             jn_int_pair(n_int, z, &a, &b);
+            RIM_PROF_ADD(8, t_mil);
             jv0 = a;
             if (so.np1_small) jv1 = b;
         }
@@ -223,7 +229,10 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     const double z = s * beta * sin_th * gamma_sin_xi;
 
     double jn, djn;
+    RIM_PROF_T(t_bes);
     sym_bessel_pair(so, z, jn, djn);
+    RIM_PROF_ADD(2, t_bes);
+    RIM_PROF_T(t_f);
     const double mj = m * jn;
     const double njp = big_n * djn;
 
@@ -242,6 +251,7 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
         f_term = dfdg + dfdcx_factor * dfdcx;
     }
 
+    RIM_PROF_ADD(6, t_f);
     return gamma * gamma * pol_term * f_term;
 }
 

@@ -163,6 +163,11 @@ struct SymArgs {
     unsigned long long hb_task;
 };
 
+#if defined(RIM_PROF)
+#define RIM_PROF_ROWS 32768
+__device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 16];
+#endif
+
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
 __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 
@@ -284,6 +289,7 @@ __device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slo
 template <int KIND>
 __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 {
+    RIM_PROF_T(t_kernel);
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
     __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
@@ -504,7 +510,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             }
             int st = 0;
             const unsigned long long e0 = wall_clock64();
+            RIM_PROF_T(t_req);
             const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, st);
+            RIM_PROF_ADD(9, t_req);
             eval_ticks += wall_clock64() - e0;
             if (shared) {
                 if (lane == 0) {
@@ -570,6 +578,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         }
     }
 
+    RIM_PROF_ADD(0, t_kernel);
     __syncthreads();
     if (g.lane == 0) {
         atomicAdd(a.queue + 1, s_qpark.ctr.samples);
@@ -1154,6 +1163,17 @@ extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[16])
 {
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+#if defined(RIM_PROF)
+    {   // diagnostic build: the 16 words are the region timers summed over waves (then reset)
+        static unsigned long long hostbuf[RIM_PROF_ROWS * 16];
+        HIP_TRY(hipMemcpyFromSymbol(hostbuf, HIP_SYMBOL(g_rim_prof), sizeof hostbuf));
+        for (int k = 0; k < 16; k++) out[k] = 0;
+        for (size_t r = 0; r < RIM_PROF_ROWS; r++) for (int k = 0; k < 16; k++) out[k] += hostbuf[r * 16 + k];
+        memset(hostbuf, 0, sizeof hostbuf);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rim_prof), hostbuf, sizeof hostbuf));
+        return RIMPHONY_OK;
+    }
+#endif
     HIP_TRY(hipMemcpy(out, c->d_queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RIMPHONY_OK;
 }

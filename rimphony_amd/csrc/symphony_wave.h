@@ -118,6 +118,7 @@ __device__ __forceinline__ SymOrder uniform_order(SymOrder so)
     for (int k = 0; k < 2; k++) {
         LeungOrder &o = *os[k];
         o.n = uni(o.n); o.thr_lo = uni(o.thr_lo); o.thr_hi = uni(o.thr_hi); o.thr_plus_lo = uni(o.thr_plus_lo);
+        o.r_lo_dn = uni(o.r_lo_dn); o.r_hi_up = uni(o.r_hi_up); o.rp_dn = uni(o.rp_dn); o.rp_up = uni(o.rp_up);
         o.ninv = uni(o.ninv); o.np1 = uni(o.np1); o.vsum2 = uni(o.vsum2); o.lgam = uni(o.lgam);
         o.small_eps_const = uni(o.small_eps_const); o.big_n = uni(o.big_n);
     }
@@ -279,10 +280,12 @@ template <int KIND>
 __device__ __forceinline__ double sym_eval_request(const SymPoint &pt, const DistParams &dist, const GKLane &g,
                                                    const IStore &inner, QagPark *qpark, double n, int lobe, int &st)
 {
+    RIM_PROF_T(t_setup);
     const SymOrder so = uniform_order(sym_order(n));
     GammaLimits L = gamma_limits(pt, n, lobe);
     L.g0 = uni(L.g0);
     L.g1 = uni(L.g1);
+    RIM_PROF_ADD(7, t_setup);
     auto f = [&](double x, bool active) -> double {
         return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
     };

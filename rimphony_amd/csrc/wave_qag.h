@@ -123,7 +123,7 @@ __device__ __forceinline__ double rescale_error(double err, double result_abs, d
 {
     err = rim_fabs(err);
     if (result_asc != 0 && err != 0) {
-        const double scale = rim_pow((200 * err / result_asc), 1.5);
+        const double scale = rim_pow15(200 * err / result_asc);
         if (scale < 1) err = result_asc * scale;
         else err = result_asc;
     }
@@ -439,7 +439,9 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
                     hb_store(park->hb + 4, (unsigned long long) q.iteration);
                 }
             }
+            RIM_PROF_T(t_int);
             fv = f(x, active);
+            RIM_PROF_ADD(1, t_int);
             wv_sync();
             q = park->q;
             qag_uniformize(q);
