@@ -30,10 +30,10 @@
 
 /* Region timers of the diagnostic build (-DRIM_PROF, tools/region_profile.py); no-ops otherwise. */
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_rim_prof[];
+extern __shared__ unsigned long long rim_prof_lds[];      /* 16 words of dynamic LDS per workgroup */
 #define RIM_PROF_T(t) const unsigned long long t = __builtin_readcyclecounter()
 #define RIM_PROF_ADD(idx, t) do { if ((threadIdx.x & 63) == 0) \
-    g_rim_prof[(size_t) blockIdx.x * 16 + (idx)] += __builtin_readcyclecounter() - t; } while (0)
+    __hip_atomic_fetch_add(&rim_prof_lds[idx], __builtin_readcyclecounter() - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #else
 #define RIM_PROF_T(t)
 #define RIM_PROF_ADD(idx, t)

@@ -116,46 +116,30 @@ struct SymPoint {
 };
 
 // Order data for one gamma-integral: J_n and J_{n+1} at fixed n (wave-uniform).
+// The two LeungOrder records live in memory the caller provides -- LDS in the wave kernels -- and
+// are read where they are used: held in registers they would cost 56 SGPRs for the whole integrand
+// (the kernel then spills SGPRs into VGPR lanes inside the hot loop).
 struct SymOrder {
     double n;
     bool small;         // integer n < 30: Miller recurrence instead of the Leung expansions
     bool np1_small;     // n + 1 < 30
     bool dj_nan;        // n >= 1e15 (bessel.c:382-388)
-    LeungOrder o0, o1;  // orders n and n + 1 (valid when >= 30)
+    const LeungOrder *o;  // [2]: orders n and n + 1 (valid when >= 30)
 };
 
-RIM_DEV SymOrder sym_order(double n)
+RIM_DEV SymOrder sym_order(double n, LeungOrder *store)
 {
     SymOrder so;
     so.n = n;
     so.small = n < 30.;
     so.np1_small = (n + 1.) < 30.;
     so.dj_nan = n >= 1e15;
-    so.o0 = LeungOrder();
-    so.o1 = LeungOrder();
-    if (!so.small) so.o0 = leung_order(n);
-    if (!so.np1_small) so.o1 = leung_order(n + 1.);
+    store[0] = LeungOrder();
+    store[1] = LeungOrder();
+    if (!so.small) store[0] = leung_order(n);
+    if (!so.np1_small) store[1] = leung_order(n + 1.);
+    so.o = store;
     return so;
-}
-
-RIM_DEV LeungOrder select_order(bool second, const LeungOrder &a, const LeungOrder &b)
-{
-    LeungOrder o;
-    o.n = second ? b.n : a.n;
-    o.thr_lo = second ? b.thr_lo : a.thr_lo;
-    o.thr_hi = second ? b.thr_hi : a.thr_hi;
-    o.thr_plus_lo = second ? b.thr_plus_lo : a.thr_plus_lo;
-    o.r_lo_dn = second ? b.r_lo_dn : a.r_lo_dn;
-    o.r_hi_up = second ? b.r_hi_up : a.r_hi_up;
-    o.rp_dn = second ? b.rp_dn : a.rp_dn;
-    o.rp_up = second ? b.rp_up : a.rp_up;
-    o.ninv = second ? b.ninv : a.ninv;
-    o.np1 = second ? b.np1 : a.np1;
-    o.vsum2 = second ? b.vsum2 : a.vsum2;
-    o.lgam = second ? b.lgam : a.lgam;
-    o.small_eps_const = second ? b.small_eps_const : a.small_eps_const;
-    o.big_n = second ? b.big_n : a.big_n;
-    return o;
 }
 
 // J_n(z) and J'_n(z) as the reference's pkgw_bessel_j / pkgw_bessel_dj pair would
@@ -172,8 +156,7 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
         const bool second = w != 0;
         const bool is_small = second ? so.np1_small : so.small;
         if (!is_small) {
-            const LeungOrder o = select_order(second, so.o0, so.o1);
-            const double v = leung_j(o, z);
+            const double v = leung_j(so.o[w], z);
             if (second) jv1 = v; else jv0 = v;
         }
     }
@@ -229,6 +212,7 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     const double z = s * beta * sin_th * gamma_sin_xi;
 
     double jn, djn;
+    { RIM_PROF_T(t_cal); RIM_PROF_ADD(10, t_cal); }     // empty region: the timers' own cost
     RIM_PROF_T(t_bes);
     sym_bessel_pair(so, z, jn, djn);
     RIM_PROF_ADD(2, t_bes);

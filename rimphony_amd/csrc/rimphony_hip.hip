@@ -164,6 +164,11 @@ struct SymArgs {
 };
 
 #if defined(RIM_PROF)
+#define RIM_DYN_LDS 128             // the region timers accumulate in dynamic LDS
+#else
+#define RIM_DYN_LDS 0
+#endif
+#if defined(RIM_PROF)
 #define RIM_PROF_ROWS 32768
 __device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 16];
 #endif
@@ -289,6 +294,10 @@ __device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slo
 template <int KIND>
 __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 {
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x < 16) rim_prof_lds[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     RIM_PROF_T(t_kernel);
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
@@ -580,6 +589,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 
     RIM_PROF_ADD(0, t_kernel);
     __syncthreads();
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x < 16) g_rim_prof[(size_t) blockIdx.x * 16 + threadIdx.x] += rim_prof_lds[threadIdx.x];
+#endif
     if (g.lane == 0) {
         atomicAdd(a.queue + 1, s_qpark.ctr.samples);
         atomicAdd(a.queue + 2, s_qpark.ctr.steps);
@@ -776,7 +788,12 @@ __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const 
     dist_prepare<KIND>(d, norm_ptr[0]);
     for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
         const double n = nvals[i];
-        const SymOrder so = sym_order(n);
+        LeungOrder ord_tmp[2];
+        SymOrder so = sym_order(n, ord_tmp);
+        __syncthreads();
+        if (g.lane == 0) { s_qpark.ord[0] = ord_tmp[0]; s_qpark.ord[1] = ord_tmp[1]; }
+        __syncthreads();
+        so.o = s_qpark.ord;
         const GammaLimits L = gamma_limits(pt, n, pa.negative_lobe);
         auto f = [&](double x, bool active) -> double { return active ? gamma_integrand<KIND>(pt, d, so, x) : 0.; };
         QagState q;
@@ -970,7 +987,7 @@ static int launch_norm(rimphony_ctx *c, size_t n, const ParamPtrs &pp, double *d
     const unsigned grid = persistent_grid(c, n, 16);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(norm_kernel<KIND>, dim3(grid), dim3(64), 0, st, pp, n, d_norm, c->d_queue, c->d_spill);
+    hipLaunchKernelGGL(norm_kernel<KIND>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pp, n, d_norm, c->d_queue, c->d_spill);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }
@@ -1028,9 +1045,9 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
     // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
-    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), 0, st, b.board_flags, grid);
+    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);
     HIP_TRY(hipEventRecord(c->ev_start, st));
-    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_stop, st));
     c->ev_valid = 1;
@@ -1046,7 +1063,7 @@ static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     if (rc) return rc;
     SymArgs b = a;
     b.spill = c->d_spill;
-    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }
@@ -1095,9 +1112,9 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         const unsigned nb = (unsigned) ((n + 255) / 256);
         HIP_TRY(hipMemsetAsync(hist, 0, ORDER_BUCKETS * sizeof(unsigned), st));
         const double *gmin = (kind == RIMPHONY_POWER_LAW) ? pp.p[1] : (kind == RIMPHONY_PITCHY_PL) ? pp.p[2] : nullptr;
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, d_s, d_theta, gmin, n, hist);
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, st, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, d_s, d_theta, gmin, n, hist, c->d_perm);
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, n, hist);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), RIM_DYN_LDS, st, hist);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, n, hist, c->d_perm);
         HIP_TRY(hipGetLastError());
         a.perm = c->d_perm;
     }
@@ -1117,7 +1134,7 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, 16 * sizeof(unsigned long long), st));
     {
         const size_t total = n * 8;
-        hipLaunchKernelGGL(fill_unselected_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(fill_unselected_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), RIM_DYN_LDS, st,
                            d_out, d_status, n, computed);
         HIP_TRY(hipGetLastError());
     }
@@ -1299,7 +1316,8 @@ __global__ void integrand_kernel_n(PointArgs pa, const double *norm_ptr, size_t 
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
     dist_prepare<KIND>(d, norm_ptr[0]);
-    const SymOrder so = sym_order(n[i]);
+    LeungOrder ord[2];
+    const SymOrder so = sym_order(n[i], ord);
     out[i] = gamma_integrand<KIND>(pt, d, so, gamma[i]);
 }
 
@@ -1319,10 +1337,10 @@ extern "C" int rimphony_gamma_integrand_batch_device(rimphony_ctx *c, int kind, 
     if (rc) return rc;
     const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
     switch (kind) {
-    case 0: hipLaunchKernelGGL(integrand_kernel_n<0>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
-    case 1: hipLaunchKernelGGL(integrand_kernel_n<1>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
-    case 2: hipLaunchKernelGGL(integrand_kernel_n<2>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
-    default: hipLaunchKernelGGL(integrand_kernel_n<3>, grid, block, 0, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    case 0: hipLaunchKernelGGL(integrand_kernel_n<0>, grid, block, RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    case 1: hipLaunchKernelGGL(integrand_kernel_n<1>, grid, block, RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    case 2: hipLaunchKernelGGL(integrand_kernel_n<2>, grid, block, RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
+    default: hipLaunchKernelGGL(integrand_kernel_n<3>, grid, block, RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_gamma, d_out); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
@@ -1345,10 +1363,10 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     rc = ensure_spill(c, grid);
     if (rc) return rc;
     switch (kind) {
-    case 0: hipLaunchKernelGGL(gamma_integral_kernel<0>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
-    case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
-    case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
-    default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), 0, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    case 0: hipLaunchKernelGGL(gamma_integral_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;

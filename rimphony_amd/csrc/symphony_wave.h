@@ -107,24 +107,6 @@ __device__ __forceinline__ void task_uniformize(TaskState &T)
     qag_uniformize(T.oq);
 }
 
-__device__ __forceinline__ SymOrder uniform_order(SymOrder so)
-{
-    so.n = uni(so.n);
-    so.small = uni(so.small);
-    so.np1_small = uni(so.np1_small);
-    so.dj_nan = uni(so.dj_nan);
-    LeungOrder *os[2] = { &so.o0, &so.o1 };
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        LeungOrder &o = *os[k];
-        o.n = uni(o.n); o.thr_lo = uni(o.thr_lo); o.thr_hi = uni(o.thr_hi); o.thr_plus_lo = uni(o.thr_plus_lo);
-        o.r_lo_dn = uni(o.r_lo_dn); o.r_hi_up = uni(o.r_hi_up); o.rp_dn = uni(o.rp_dn); o.rp_up = uni(o.rp_up);
-        o.ninv = uni(o.ninv); o.np1 = uni(o.np1); o.vsum2 = uni(o.vsum2); o.lgam = uni(o.lgam);
-        o.small_eps_const = uni(o.small_eps_const); o.big_n = uni(o.big_n);
-    }
-    return so;
-}
-
 // ---- the coefficient as a resumable computation -------------------------------------------
 //
 //   sym_begin    initialise the task state
@@ -281,7 +263,14 @@ __device__ __forceinline__ double sym_eval_request(const SymPoint &pt, const Dis
                                                    const IStore &inner, QagPark *qpark, double n, int lobe, int &st)
 {
     RIM_PROF_T(t_setup);
-    const SymOrder so = uniform_order(sym_order(n));
+    // every lane computes the (uniform) order data; lane 0 files it in LDS for the integrand
+    LeungOrder ord_tmp[2];
+    SymOrder so = sym_order(n, ord_tmp);
+    wv_sync();                       // nobody is still reading the previous request's records
+    if (g.lane == 0) { qpark->ord[0] = ord_tmp[0]; qpark->ord[1] = ord_tmp[1]; }
+    wv_sync();
+    so.n = uni(so.n); so.small = uni(so.small); so.np1_small = uni(so.np1_small); so.dj_nan = uni(so.dj_nan);
+    so.o = qpark->ord;
     GammaLimits L = gamma_limits(pt, n, lobe);
     L.g0 = uni(L.g0);
     L.g1 = uni(L.g1);

@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include "detmath.h"
+#include "dev_bessel.h"
 #include "gk31_table.h"
 
 namespace rim {
@@ -390,6 +391,7 @@ struct WaveCounters {
 // integrand runs, so that the integrand has the vector register file to itself.
 struct QagPark {
     QagState q;
+    LeungOrder ord[2];        // order records of the gamma-integral being evaluated (dev_symphony.h: SymOrder)
     WaveCounters ctr;
     unsigned long long *hb;   // optional heartbeat words in host-mapped memory (diagnostics), else null
 };

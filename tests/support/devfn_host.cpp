@@ -14,7 +14,8 @@ double devh_gamma_integrand(int kind, int coeff, int stokes, double s, double co
     SymPoint pt{s, cos_th, sin_th, coeff, stokes};
     DistParams d;
     for (int i = 0; i < 5; i++) d.par[i] = par[i];
-    SymOrder so = sym_order(n);
+    LeungOrder ord[2];
+    SymOrder so = sym_order(n, ord);
     switch (kind) {
     case 0: dist_prepare<0>(d, norm); return gamma_integrand<0>(pt, d, so, gamma);
     case 1: dist_prepare<1>(d, norm); return gamma_integrand<1>(pt, d, so, gamma);
