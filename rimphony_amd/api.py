@@ -138,7 +138,7 @@ class Context:
         return float(ms.value)
 
     def debug_counters(self):
-        arr = (ctypes.c_uint64 * 16)()
+        arr = (ctypes.c_uint64 * 32)()
         capi.check(self.lib.rimphony_debug_counters(self.handle, arr), "rimphony_debug_counters")
         return [int(v) for v in arr]
 

@@ -65,6 +65,18 @@ __device__ __forceinline__ double rim_fma_k(double a, double b, double k)
 #else
 #define rim_fma_k(a, b, k) rim_fma(a, b, k)
 #endif
+/* a / b given binv = RN(1 / b): the correctly rounded quotient in 3 operations instead of the
+ * ~11-instruction IEEE division sequence (Markstein: q = RN(a binv), r = a - q b exactly by FMA,
+ * RN(q + r binv) = RN(a / b)).  For finite a, normal b and a quotient in the normal range -- the
+ * divisors it is used with are harmonic numbers >= 30 and literals.  tests/test_detmath.py checks
+ * it against the division operator. */
+RIM_FN double rim_div_by(double a, double b, double binv)
+{
+    const double q = a * binv;
+    const double r = rim_fma(-q, b, a);
+    return rim_fma(r, binv, q);
+}
+
 RIM_FN double rim_sqrt(double x) { return __builtin_sqrt(x); }
 RIM_FN double rim_fabs(double x) { return __builtin_fabs(x); }
 RIM_FN double rim_floor(double x) { return __builtin_floor(x); }

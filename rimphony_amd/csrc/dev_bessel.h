@@ -52,8 +52,12 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
         q = rim_fma_k(q, x, 6720.);
         q = rim_fma_k(q, x, 20160.);
         q = rim_fma_k(q, x, 40320.);
-        return f_factor * (1 + (q * x / 40320.));
+        return f_factor * (1 + rim_div_by(q * x, 40320., 1. / 40320.));
     }
+    // exp(-760) and exp(log|f| - 760) are exactly 0 for |f| < 1e6 (rim_exp returns 0 below -745.2), so
+    // both arms of the large-exponent branch below give f_factor * 0: skip its log and exp.  Most
+    // samples of a gamma-integral lie far out on the exponentially small side of J_n.
+    if (f_exp < -760. && rim_fabs(f_factor) < 1e6) return f_factor * 0.;
     if (a > 690.) {
         const double sign_f = (f_factor < 0) ? -1. : 1.;
         const double log_f = rim_log(rim_fabs(f_factor));
@@ -120,8 +124,8 @@ RIM_DEV LeungOrder leung_order(double n)
 RIM_DEV double meissel_first(const LeungOrder &o, double x)
 {
     const double n = o.n;
-    const double z = x / n;
-    const double eps = (n - x) / n;
+    const double z = rim_div_by(x, n, o.ninv);
+    const double eps = rim_div_by(n - x, n, o.ninv);
     const double Z = rim_sqrt(eps * (1 + z));
     const double U = 1. / (n * Z * Z * Z);
     const double t = z * z;
@@ -172,7 +176,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     v = rim_fma(v, U, a2);
     v = rim_fma(v, U, a1);
     v = rim_fma(v, U, a0);
-    const double vsum1 = (U * v) / 0.10321920e8;
+    const double vsum1 = rim_div_by(U * v, 0.10321920e8, 1. / 0.10321920e8);
 
     const double factor = 1. / (o.np1 * rim_sqrt(Z));
 
@@ -184,7 +188,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
         q = rim_fma_k(q, eps, 0.303114240e9);
         q = rim_fma_k(q, eps, 0.442810368e9);
         q = rim_fma_k(q, eps, 0.984023040e9);
-        const double exp2 = -n * rim_sqrt(2. * eps) * eps * q / 0.1476034560e10;
+        const double exp2 = rim_div_by(-n * rim_sqrt(2. * eps) * eps * q, 0.1476034560e10, 1. / 0.1476034560e10);
         exp_val = o.small_eps_const + exp2 - vsum1 - o.vsum2;
     } else {
         double invZp1;
@@ -200,9 +204,14 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
         } else {
             invZp1 = 1. / (1. + Z);
         }
+        RIM_PROF_T(t_ml);
         exp_val = n * (rim_log(x * invZp1) - (1 - Z)) - vsum1 - o.vsum2 - o.lgam;
+        RIM_PROF_ADD(15, t_ml);
     }
-    return exp_factor(factor, exp_val);
+    RIM_PROF_T(t_me);
+    const double mres = exp_factor(factor, exp_val);
+    RIM_PROF_ADD(16, t_me);
+    return mres;
 }
 
 // Debye epsilon expansion (bessel.c:159-213): degree-15 polynomial in ez = x - n.
@@ -211,7 +220,9 @@ RIM_DEV double debye_eps(double n, double x)
     if (x > 1.e55) return RIM_NAN;
 
     const double ez = x - n;
+    RIM_PROF_T(t_dp);
     const double z = rim_pow(x, 1. / 3.);
+    RIM_PROF_ADD(17, t_dp);
     const double t3 = z * z;
     const double t4 = x * z;
     const double t10 = t4 * t4;
@@ -283,7 +294,7 @@ RIM_DEV double leung_j(const LeungOrder &o, double x)
     if (x == n) {
         need_debye = true; need_meissel = false;
     } else if (x < n) {
-        const double r = (n - x) / n;
+        const double r = rim_div_by(n - x, n, o.ninv);
         if (r < o.r_lo_dn) { need_debye = true; need_meissel = false; }
         else if (r > o.r_hi_up) { need_debye = false; need_meissel = true; }
         else {

@@ -164,13 +164,13 @@ struct SymArgs {
 };
 
 #if defined(RIM_PROF)
-#define RIM_DYN_LDS 128             // the region timers accumulate in dynamic LDS
+#define RIM_DYN_LDS 256             // the region timers accumulate in dynamic LDS
 #else
 #define RIM_DYN_LDS 0
 #endif
 #if defined(RIM_PROF)
 #define RIM_PROF_ROWS 32768
-__device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 16];
+__device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 32];
 #endif
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
@@ -295,7 +295,7 @@ template <int KIND>
 __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 {
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
-    if (threadIdx.x < 16) rim_prof_lds[threadIdx.x] = 0;
+    if (threadIdx.x < 32) rim_prof_lds[threadIdx.x] = 0;
     __syncthreads();
 #endif
     RIM_PROF_T(t_kernel);
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     RIM_PROF_ADD(0, t_kernel);
     __syncthreads();
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
-    if (threadIdx.x < 16) g_rim_prof[(size_t) blockIdx.x * 16 + threadIdx.x] += rim_prof_lds[threadIdx.x];
+    if (threadIdx.x < 32) g_rim_prof[(size_t) blockIdx.x * 32 + threadIdx.x] += rim_prof_lds[threadIdx.x];
 #endif
     if (g.lane == 0) {
         atomicAdd(a.queue + 1, s_qpark.ctr.samples);
@@ -1181,11 +1181,11 @@ extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[16])
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
 #if defined(RIM_PROF)
-    {   // diagnostic build: the 16 words are the region timers summed over waves (then reset)
-        static unsigned long long hostbuf[RIM_PROF_ROWS * 16];
+    {   // diagnostic build: 32 region timers summed over waves (then reset); out must hold 32 words
+        static unsigned long long hostbuf[RIM_PROF_ROWS * 32];
         HIP_TRY(hipMemcpyFromSymbol(hostbuf, HIP_SYMBOL(g_rim_prof), sizeof hostbuf));
-        for (int k = 0; k < 16; k++) out[k] = 0;
-        for (size_t r = 0; r < RIM_PROF_ROWS; r++) for (int k = 0; k < 16; k++) out[k] += hostbuf[r * 16 + k];
+        for (int k = 0; k < 32; k++) out[k] = 0;
+        for (size_t r = 0; r < RIM_PROF_ROWS; r++) for (int k = 0; k < 32; k++) out[k] += hostbuf[r * 32 + k];
         memset(hostbuf, 0, sizeof hostbuf);
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rim_prof), hostbuf, sizeof hostbuf));
         return RIMPHONY_OK;

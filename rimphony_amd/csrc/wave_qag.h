@@ -289,12 +289,22 @@ __device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane
             const int s = ist_stamp(st, i);
             if (e > be || (e == be && s > bs)) { be = e; bs = s; bi = i; }
         }
+        // The largest error first (one max per butterfly step); the (error, stamp) tie-break of the
+        // sorted list only matters when two lanes hold that same error, which is rare.
+        double top = be;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const double oe = wv_shfl_xor(be, m);
-            const int os = wv_shfl_xor(bs, m);
-            const int oi = wv_shfl_xor(bi, m);
-            if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+        for (int m = 1; m < 64; m <<= 1) top = __builtin_fmax(top, wv_shfl_xor(top, m));
+        const unsigned long long holders = wv_ballot(be == top);
+        if (__builtin_popcountll(holders) == 1) {
+            bi = wv_readlane(bi, __builtin_ffsll((long long) holders) - 1);
+        } else {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const double oe = wv_shfl_xor(be, m);
+                const int os = wv_shfl_xor(bs, m);
+                const int oi = wv_shfl_xor(bi, m);
+                if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+            }
         }
         imax = wv_readfirstlane(bi);
     }
@@ -422,7 +432,9 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
             la = a; lb = b;
             active = g.node && g.half == 0;
         } else {
+            RIM_PROF_T(t_pick);
             qag_pick(q, st, g.lane);
+            RIM_PROF_ADD(13, t_pick);
             la = g.half ? q.a2 : q.a1;
             lb = g.half ? q.b2 : q.b1;
             active = g.node;
@@ -444,13 +456,17 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
             RIM_PROF_T(t_int);
             fv = f(x, active);
             RIM_PROF_ADD(1, t_int);
+            RIM_PROF_T(t_unpark);
             wv_sync();
             q = park->q;
             qag_uniformize(q);
+            RIM_PROF_ADD(14, t_unpark);
         }
         if (first) {
             const double hl = 0.5 * (b - a);
+            RIM_PROF_T(t_gk);
             const GKRes r = wave_gk31(fv, hl, g);
+            RIM_PROF_ADD(11, t_gk);
             first = false;
             if (qag_after_first(q, st, g.lane, a, b, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
                                 readlane_d(r.resabs, 0), readlane_d(r.resasc, 0)))
@@ -459,11 +475,15 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
             const double la2 = g.half ? q.a2 : q.a1;
             const double lb2 = g.half ? q.b2 : q.b1;
             const double hl = 0.5 * (lb2 - la2);
+            RIM_PROF_T(t_gk);
             const GKRes r = wave_gk31(fv, hl, g);
-            if (qag_after_bisect(q, st, g.lane,
+            RIM_PROF_ADD(11, t_gk);
+            RIM_PROF_T(t_ab);
+            const bool fin = qag_after_bisect(q, st, g.lane,
                                  readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
-                                 readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32)))
-                return;
+                                 readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+            RIM_PROF_ADD(12, t_ab);
+            if (fin) return;
         }
     }
 }

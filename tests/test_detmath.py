@@ -20,6 +20,10 @@ double t_pow(double x,double y){return rim_pow(x,y);}
 double t_lgamma(double x){return rim_lgamma_pos(x);}
 double t_sin(double x){double s,c;rim_sincos(x,&s,&c);return s;}
 double t_cos(double x){double s,c;rim_sincos(x,&s,&c);return c;}
+/* mismatches of rim_div_by against the division operator over n pairs */
+long t_div_by_mismatches(const double *a, const double *b, long n)
+{ long bad = 0; for (long i = 0; i < n; i++) { if (rim_div_by(a[i], b[i], 1.0 / b[i]) != a[i] / b[i]) bad++; } return bad; }
+double t_pow15(double x){return rim_pow15(x);}
 '''
 
 
@@ -90,3 +94,29 @@ def test_lgamma_sincos(dm):
     th = np.concatenate([rng.uniform(-4, 4, 1500), rng.uniform(-1e5, 1e5, 1500), rng.uniform(0, 1.6, 1000)])
     assert worst(dm.t_sin, mp.sin, th) < 1.5
     assert worst(dm.t_cos, mp.cos, th) < 1.5
+
+
+def test_div_by_is_the_correctly_rounded_quotient(dm):
+    """rim_div_by (3 operations, reciprocal supplied) must return exactly a / b for the divisors it is used
+    with in the kernels: harmonic numbers (integers and non-integers >= 30) and the literal denominators."""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    b = np.concatenate([30. + np.floor(rng.random(n) * 1e6), 30. + rng.random(n) * 1e7,
+                        np.full(n // 2, 0.10321920e8), np.full(n // 2, 0.1476034560e10), np.full(n // 2, 40320.)])
+    a = np.concatenate([rng.random(n) * b[:n], b[n:2 * n] * (1. - rng.random(n)),
+                        np.exp(rng.random(3 * (n // 2)) * 200. - 100.) * (rng.random(3 * (n // 2)) - 0.5)])
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    dm.t_div_by_mismatches.restype = ctypes.c_long
+    dm.t_div_by_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    assert dm.t_div_by_mismatches(a.ctypes.data, b.ctypes.data, len(a)) == 0
+
+
+def test_pow15(dm):
+    dm.t_pow15.restype = ctypes.c_double
+    dm.t_pow15.argtypes = [ctypes.c_double]
+    mp.mp.prec = 200
+    rng = np.random.default_rng(6)
+    for x in np.exp(rng.random(2000) * 60. - 40.):
+        ref = mp.mpf(float(x)) ** mp.mpf(1.5)
+        got = dm.t_pow15(float(x))
+        assert abs((mp.mpf(got) - ref) / ref) < 3e-16

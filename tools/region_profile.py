@@ -21,7 +21,8 @@ w = ctx.last_work()
 c = ctx.debug_counters()
 names = ["kernel (wave lifetime)", "integrand (f call in wave_qag)", "  bessel pair", "    region select (log10)", "    debye bodies",
          "    meissel bodies", "  distribution term", "request setup (sym_order, gamma_limits)", "    miller (integer orders)",
-         "requests (sym_eval_request)", "empty region (timer cost, once per pass)"]
+         "requests (sym_eval_request)", "empty region (timer cost, once per pass)", "wave_gk31 (+rescale_error)", "qag_after_bisect", "qag_pick",
+         "unpark (sync + LDS reload + uniformize)", "      meissel: log + exp_val", "      meissel: exp_factor", "      debye: pow(x, 1/3)"]
 print("kernel ms %.1f  samples %d passes %d" % (ctx.last_symphony_ms(), w["samples"], w["passes"]))
 for k, nm in enumerate(names):
     print("%-45s %6.2f %%   %8.1f cycles/pass" % (nm, 100. * c[k] / c[0], c[k] / max(w["passes"], 1)))
