@@ -34,9 +34,12 @@ extern __shared__ unsigned long long rim_prof_lds[];      /* 16 words of dynamic
 #define RIM_PROF_T(t) const unsigned long long t = __builtin_readcyclecounter()
 #define RIM_PROF_ADD(idx, t) do { if ((threadIdx.x & 63) == 0) \
     __hip_atomic_fetch_add(&rim_prof_lds[idx], __builtin_readcyclecounter() - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define RIM_PROF_COUNT(idx, v) do { if ((threadIdx.x & 63) == 0) \
+    __hip_atomic_fetch_add(&rim_prof_lds[idx], (unsigned long long) (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #else
 #define RIM_PROF_T(t)
 #define RIM_PROF_ADD(idx, t)
+#define RIM_PROF_COUNT(idx, v)
 #endif
 
 #define RIM_NAN (__builtin_nan(""))

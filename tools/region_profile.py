@@ -26,3 +26,4 @@ names = ["kernel (wave lifetime)", "integrand (f call in wave_qag)", "  bessel p
 print("kernel ms %.1f  samples %d passes %d" % (ctx.last_symphony_ms(), w["samples"], w["passes"]))
 for k, nm in enumerate(names):
     print("%-45s %6.2f %%   %8.1f cycles/pass" % (nm, 100. * c[k] / c[0], c[k] / max(w["passes"], 1)))
+
