@@ -196,8 +196,14 @@ __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 //           loads) belonged to it and stays valid until this claimer reports `done`.
 //   result: res[k], status[k] (sc1 stores) -> s_waitcnt vmcnt(0) -> atomicAdd(done)
 //   owner:  poll done == count -> read res[] (sc1 loads) -> claim = (seq << 32) (closed)
-// Idle waves poll only the 64 hint words, with exponential back-off, and count themselves in
-// flags[2] so that owners publish only when somebody can actually help.
+// Discovery: there are 64 hint lines; an idle wave polls ONE of them (its index mod 64: one sc1 load
+// per poll, with exponential back-off) and looks at a slot's claim word only when the hint it
+// sees has changed.  An owner advertises a batch on every hint line of one "channel"
+// (line & (span - 1) == channel), where span ~ the number of waves that still own a task: with
+// 100 owners each batch is seen by 1/64 of the idle waves, with 2 owners by half of them, yet the
+// polls stay spread over 64 lines.  (All waves polling the same few lines -- and a per-poll look at
+// the claim word -- was measured to slow the computing waves several-fold.)
+// Idle waves count themselves in flags[IDLE] so that owners publish only when somebody can help.
 struct AssistSlot {
     unsigned long long claim;
     unsigned long long point;
@@ -224,11 +230,13 @@ __device__ __forceinline__ unsigned long long bget(const unsigned long long *p)
 __device__ __forceinline__ int bget(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned bget(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Flag words; each lives in its own 128-byte line, because thousands of waves poll them.
 #define BOARD_FLAG_EXHAUSTED 0
-#define BOARD_FLAG_ACTIVE 1
-#define BOARD_FLAG_IDLE 2
-#define BOARD_HINTS 16          // flags[16 .. 79]: slot index + 1 of a recently published batch
-#define BOARD_FLAG_WORDS 80
+#define BOARD_FLAG_ACTIVE 32
+#define BOARD_FLAG_IDLE 64
+#define BOARD_HINTS 96          // 64 hint lines (stride 32 words): (seq << 16) | (slot + 1) of a published batch
+#define BOARD_HINT_STRIDE 32
+#define BOARD_FLAG_WORDS (BOARD_HINTS + 64 * BOARD_HINT_STRIDE)
 
 __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v)
 {
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     size_t own_i = 0;
     int own_slot = 0;
     bool have_task = false, helper = false;
-    unsigned scan_rot = blockIdx.x;
+    unsigned last_hint = 0;                // lane 0: the hint whose batch this wave has already seen exhausted
 
     __builtin_amdgcn_s_setprio(3);
     for (;;) {
@@ -434,39 +442,59 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 }
                 drain_vmem();
                 __syncthreads();
-                if (lane == 0) {
+                if (lane == 0)
                     __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) cnt << 8),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&hints[(blockIdx.x + seq) & (hint_span(act) - 1u)], (unsigned) blockIdx.x + 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                drain_vmem();          // the claim word is out before anybody can see the hint
+                __syncthreads();
+                {
+                    const unsigned span = hint_span(act);
+                    const unsigned channel = ((unsigned) blockIdx.x + seq) & (span - 1u);
+                    if (((unsigned) lane & (span - 1u)) == channel)
+                        __hip_atomic_store(&hints[(unsigned) lane * BOARD_HINT_STRIDE], (seq << 16) | ((unsigned) blockIdx.x + 1u),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         } else {
-            // ---------- helper: find a published batch through the hint words ----------
-            // One lane looks at ONE hint word per poll (two sc1 loads): thousands of waves poll at the
-            // end of a launch, and wave-wide polling of all hints measurably slows the waves that compute.
+            // ---------- helper: find a published batch through this wave's hint line ----------
             unsigned h = 0, act = 1;
+            int leave = 0;
             unsigned long long c = 0;
             if (lane == 0) {
-                act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                h = __hip_atomic_load(&hints[scan_rot & (hint_span(act) - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h != 0 && h <= nboard) {
-                    c = __hip_atomic_load(&a.board[h - 1].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!claim_open(c)) h = 0;
+                if ((n_polls & 15ull) == 0) {
+                    act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // More idle waves than the remaining owners can feed (a batch has <= 62 requests) only
+                    // add polling traffic, which slows the waves that compute: the surplus leaves.
+                    const unsigned keep = act * 96u + 128u;
+                    if (counted_idle && act != 0 &&
+                        __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > keep) {
+                        const unsigned before = __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (before > keep) leave = 1;
+                        else __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (!leave)
+                    h = __hip_atomic_load(&hints[((unsigned) blockIdx.x & 63u) * BOARD_HINT_STRIDE], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned hs = h & 0xffffu;
+                if (h != last_hint && hs != 0 && hs <= nboard) {
+                    c = __hip_atomic_load(&a.board[hs - 1].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!claim_open(c)) { last_hint = h; h = 0; }      // nothing left of that batch: wait for a new hint
                 } else {
                     h = 0;
                 }
             }
             h = (unsigned) __builtin_amdgcn_readfirstlane((int) h);
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
+            if (__builtin_amdgcn_readfirstlane(leave)) break;
             n_polls += 1;
-            scan_rot += 1;
             if (h == 0) {
                 if (act == 0) break;       // every task is finished
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
                 if (backoff < 16) backoff *= 2;
                 continue;
             }
+            h &= 0xffffu;
             const unsigned long long cw = bcast_u64(c);
             src = a.board + (h - 1u);
             src_seq = (unsigned) (cw >> 32);
@@ -538,6 +566,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         if (helper) {
             if (got == 0) {
                 // every request of that batch was already taken: back off before looking again
+                // (last_hint is not set here: the claim word is re-read on the next poll, and that
+                // poll files the hint away once the batch shows no open request)
                 n_empty_claims += 1;
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
                 if (backoff < 16) backoff *= 2;
@@ -610,7 +640,8 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
 __global__ void board_init_kernel(unsigned *flags, unsigned active)
 {
     const unsigned i = threadIdx.x;
-    if (blockIdx.x == 0 && i < BOARD_FLAG_WORDS) flags[i] = (i == BOARD_FLAG_ACTIVE) ? active : 0u;
+    if (blockIdx.x == 0)
+        for (unsigned k = i; k < BOARD_FLAG_WORDS; k += blockDim.x) flags[k] = (k == BOARD_FLAG_ACTIVE) ? active : 0u;
 }
 
 // ------------------------------------------------------------------------------

@@ -26,3 +26,11 @@ if os.environ.get("AB_BIG"):
     run(0, 4096, "4096")
     run(0, 16384, "16384")
     run(0, 65536, "65536")
+if os.environ.get("AB_OUTLIER_BATCH"):
+    run(196608, 65536, "batch3(outlier)")
+    run(222883 - 2048, 4096, "4096 around outlier")
+if os.environ.get("AB_SCAN"):
+    for n in (1, 2, 8, 64, 512):
+        run(222883, n, "from outlier")
+    for n in (8, 64):
+        run(222883 - n + 1, n, "ending at outlier")
