@@ -6,11 +6,11 @@ synthetic table of random (s, theta, p, gamma_min) defined in
 rimphony_amd/workload.py, coefficients j_I and alpha_I, fp64.  A "step" is one
 pass of the hot path (full_calculation + the selected coefficients) over one
 batch of `--points` consecutive table rows PER GPU (default 262144, i.e. about a
-quarter of the table per launch); successive steps walk through the table.  Steps
-are large on purpose: the table contains rare points that are 100-1000x the mean
-cost (the reference would print "SLOW" for them, tests/symphony.rs:63-67); one such
-point keeps a single wave busy for ~8 s, which a ~9 s launch hides and a 2 s launch
-does not ("tail").  With N GPUs the step's global batch of N*points rows is
+quarter of the table per launch); successive steps walk through the table.  The
+table contains rare points that are 100-1000x the mean cost (the reference would
+print "SLOW" for them, tests/symphony.rs:63-67); the kernel's cooperative tail
+ spreads such a point over the idle waves at the end of a
+launch, so a launch with one costs ~0.2 s more than one without.  With N GPUs the step's global batch of N*points rows is
 sharded interleaved (row i -> rank i mod N, no data-path collective during
 compute) and the output table is gathered to rank 0 with one RCCL gather inside
 the timed region.  Inputs are resident in HBM before the timed region starts.
@@ -40,6 +40,11 @@ sys.path.insert(0, ROOT)
 # (Debye 21 %, Meissel-1 73 %, blend 5 %, integer order 1 %).
 FLOPS_PER_SAMPLE = 720.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
+# HBM-side bytes of symphony_kernel measured with rocprofv3 PMC (FETCH_SIZE and WRITE_SIZE, separate passes,
+# KB -> bytes; narrow accesses, so the gfx950 "wide read" doubling does not apply) on one 65536-row launch of
+# this table: profiles/r1_final_pmc_symphony_65536pts.json.  Nearly all of it is scratch (register spill)
+# traffic; it scales with the sample count, hence the per-sample figure.  Algorithmic bytes are ~150 B/point.
+PMC_BYTES_PER_SAMPLE = (1.0728e8 + 2.3432e8) * 1024. / 34183153687.
 
 
 def main():
@@ -132,9 +137,11 @@ def main():
         achieved = avg_samples * FLOPS_PER_SAMPLE / avg_kernel_s / 1e12
         roofline = {
             "bound": "valu_fp64", "achieved": round(achieved, 4), "peak": FP64_VECTOR_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / FP64_VECTOR_PEAK_TFLOPS, 5), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / FP64_VECTOR_PEAK_TFLOPS, 5),
+            "traffic": round(PMC_BYTES_PER_SAMPLE * avg_samples),
             "kernel": "symphony_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
             "samples_per_launch": avg_samples, "flops_per_sample": FLOPS_PER_SAMPLE,
+            "traffic_note": "bytes/launch = PMC bytes/sample (profiles/r1_final_pmc_symphony_65536pts.json) x samples",
         }
 
         cpu = None

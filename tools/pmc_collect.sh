@@ -11,7 +11,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_V
            "SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_SALU" \
            "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
-           "FETCH_SIZE WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+           "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/one_batch.py $N > $OUT/log$i.txt 2>&1 || { tail -5 $OUT/log$i.txt; exit 1; }
 done
