@@ -109,6 +109,8 @@ int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
  * with HIP events recorded on the stream the kernel was launched on (waits for
  * the kernel to finish). */
 int rimphony_last_symphony_ms(rimphony_ctx *ctx, float *ms);
+/* Same for the Faraday (Heyvaerts) launch of the most recent batch call. */
+int rimphony_last_faraday_ms(rimphony_ctx *ctx, float *ms);
 
 /* Diagnostics: 16 heartbeat words in host-mapped memory, updated by the wave that
  * works on task number `task` (= point * nslots + slot index) of subsequent

@@ -137,6 +137,11 @@ class Context:
         capi.check(self.lib.rimphony_last_symphony_ms(self.handle, ctypes.byref(ms)), "rimphony_last_symphony_ms")
         return float(ms.value)
 
+    def last_faraday_ms(self):
+        ms = ctypes.c_float()
+        capi.check(self.lib.rimphony_last_faraday_ms(self.handle, ctypes.byref(ms)), "rimphony_last_faraday_ms")
+        return float(ms.value)
+
     def debug_counters(self):
         arr = (ctypes.c_uint64 * 32)()
         capi.check(self.lib.rimphony_debug_counters(self.handle, arr), "rimphony_debug_counters")

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("RIMPHONY_HIP_LIB") or os.path.join(_HERE, "librimphon
 
 SYMBOLS = [
     "rimphony_dist_nparams", "rimphony_ctx_create", "rimphony_ctx_destroy", "rimphony_strerror",
-    "rimphony_version", "rimphony_last_work", "rimphony_last_symphony_ms", "rimphony_debug_heartbeat", "rimphony_debug_counters", "rimphony_batch_compute_device", "rimphony_batch_compute",
+    "rimphony_version", "rimphony_last_work", "rimphony_last_symphony_ms", "rimphony_last_faraday_ms", "rimphony_debug_heartbeat", "rimphony_debug_counters", "rimphony_batch_compute_device", "rimphony_batch_compute",
     "rimphony_batch_norm_device", "rimphony_bessel_batch_device", "rimphony_gamma_integrand_batch_device",
     "rimphony_gamma_integral_batch_device", "rimphony_qag_selftest_device",
 ]
@@ -54,6 +54,8 @@ def load():
     lib.rimphony_last_work.argtypes = [c_void_p, POINTER(Work)]
     lib.rimphony_last_symphony_ms.restype = c_int
     lib.rimphony_last_symphony_ms.argtypes = [c_void_p, POINTER(ctypes.c_float)]
+    lib.rimphony_last_faraday_ms.restype = c_int
+    lib.rimphony_last_faraday_ms.argtypes = [c_void_p, POINTER(ctypes.c_float)]
     lib.rimphony_debug_counters.restype = c_int
     lib.rimphony_debug_counters.argtypes = [c_void_p, POINTER(c_uint64)]
     lib.rimphony_debug_heartbeat.restype = c_int

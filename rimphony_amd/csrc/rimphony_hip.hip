@@ -41,6 +41,7 @@ using namespace rim;
 // allocator spills 47 VGPRs to scratch and still wins)
 #ifndef RIM_SYM_WAVES
 #define RIM_SYM_WAVES 6
+#define RIM_HEY_WAVES 2          // heyvaerts: ~200 VGPRs
 #endif
 
 // ------------------------------------------------------------------------------
@@ -299,8 +300,77 @@ __device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slo
     d.neg_inverse_t = uni(d.neg_inverse_t);
 }
 
+// ---- the two problems the cooperative kernel runs ------------------------------------------
+// A problem supplies the uniform context of a task, the parked task state and the five steps of
+// the resumable computation (begin / post / eval / consume / result).  Requests and results have
+// the same shape in both: (double abscissa, int tag) -> (double value, int status).
 template <int KIND>
-__global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
+struct SymphonyProblem {
+    struct Ctx { SymPoint pt; DistParams d; };
+    typedef TaskState Task;
+    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0 };
+    static __device__ __forceinline__ void init(Ctx &) {}
+    static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
+    { load_context<KIND>(a, i, slot, c.pt, c.d, norm); }
+    static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { sym_begin(c.pt, T); }
+    static __device__ __forceinline__ void uniformize(Task &T) { task_uniformize(T); }
+    static __device__ __forceinline__ bool done(const Task &T) { return T.phase == PH_DONE; }
+    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
+    { sym_post(c.pt, g, outer, T, B); }
+    static __device__ __forceinline__ double eval(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+                                                  double x, int tag, int &st)
+    { return sym_eval_request<KIND>(c.pt, c.d, g, inner, qp, x, tag, st); }
+    static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
+                                                   const SymBatch &B, double gval, int bst)
+    { sym_consume(c.pt, g, outer, T, B, gval, bst); }
+    static __device__ __forceinline__ double result(const Ctx &c, const Task &T, int &st) { return sym_result(c.pt, T, st); }
+};
+
+template <int KIND>
+struct HeyvaertsProblem {
+    struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
+    typedef HeyTask Task;
+    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62 };
+    static __device__ __forceinline__ void init(Ctx &c)
+    {
+        c.hc = hey_consts();
+        c.hc.g_p23 = uni(c.hc.g_p23); c.hc.g_m23 = uni(c.hc.g_m23); c.hc.g_p13 = uni(c.hc.g_p13); c.hc.g_m13 = uni(c.hc.g_m13);
+    }
+    static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
+    {
+        HeyPoint &pt = c.pt;
+        pt.s = uni(a.s[i]);
+        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
+        pt.sin_th = uni(pt.sin_th);
+        pt.cos_th = uni(pt.cos_th);
+        pt.sigma0 = uni(pt.s * pt.sin_th);
+        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
+        pt.stokes = uni(c_slot_stokes[slot]);
+        load_params<KIND>(a.pp, i, c.d);
+        norm = uni(a.norm[i]);
+        dist_prepare<KIND>(c.d, norm);
+#pragma unroll
+        for (int k = 0; k < 5; k++) c.d.par[k] = uni(c.d.par[k]);
+        c.d.inv_gamma_cutoff = uni(c.d.inv_gamma_cutoff);
+        c.d.inv_kappa_width = uni(c.d.inv_kappa_width);
+        c.d.neg_inverse_t = uni(c.d.neg_inverse_t);
+    }
+    static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { hey_begin(c.pt, T); }
+    static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }
+    static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
+    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
+    { hey_post(c.pt, g, outer, T, B); }
+    static __device__ __forceinline__ double eval(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+                                                  double x, int tag, int &st)
+    { return hey_eval_request<KIND>(c.pt, c.d, c.hc, g, inner, qp, x, tag, st); }
+    static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
+                                                   const SymBatch &B, double gval, int bst)
+    { hey_consume(c.pt, g, outer, T, B, gval, bst); }
+    static __device__ __forceinline__ double result(const Ctx &, const Task &T, int &st) { return hey_result(T, st); }
+};
+
+template <class P>
+__global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
 {
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
     if (threadIdx.x < 32) rim_prof_lds[threadIdx.x] = 0;
@@ -310,7 +380,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
     __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
-    __shared__ TaskState s_park;
+    __shared__ typename P::Task s_park;
     const GKLane g = gk_lane_init(s_tab);
     const int lane = g.lane;
     double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
@@ -333,8 +403,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                        n_empty_claims = 0, eval_ticks = 0, max_wait = 0;
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
-    SymPoint pt;                           // context of the requests being evaluated (own task or a helped one)
-    DistParams d;
+    typename P::Ctx cx;                    // context of the requests being evaluated (own task or a helped one)
+    P::init(cx);
+    unsigned long long *const queue = a.queue + P::QUEUE;
     // The own task's state lives in LDS (s_park) between the three places that touch it, so that it
     // never occupies registers while the integrand runs.
     size_t own_i = 0;
@@ -354,7 +425,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         if (!helper) {
             // ---------- owner: next batch of the current task (fetching a task first if needed) ----------
             if (!have_task) {
-                const unsigned long long t = wave_next_task(a.queue, lane);
+                const unsigned long long t = wave_next_task(queue, lane);
                 if (t >= ntasks) {
                     helper = true;
                     if (lane == 0) {
@@ -373,9 +444,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                 own_i = a.perm ? (size_t) a.perm[seqidx] : seqidx;
                 own_slot = a.slot[(int) (t % (unsigned) a.nslots)];
                 double norm;
-                load_context<KIND>(a, own_i, own_slot, pt, d, norm);
+                P::load(a, own_i, own_slot, cx, norm);
                 if (lane == 0) {
-                    s_qpark.hb = (a.heartbeat && t == a.hb_task) ? a.heartbeat : nullptr;
+                    s_qpark.hb = (a.heartbeat && (t | (unsigned long long) P::HB_TAG) == a.hb_task) ? a.heartbeat : nullptr;
                     if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
                 }
                 __syncthreads();
@@ -386,21 +457,21 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                     }
                     continue;
                 }
-                TaskState T0;
-                sym_begin(pt, T0);
+                typename P::Task T0;
+                P::begin(cx, T0);
                 if (lane == 0) s_park = T0;
                 __syncthreads();
                 have_task = true;
             }
             bool finished;
             {
-                TaskState T = s_park;
-                task_uniformize(T);
-                if (T.phase != PH_DONE) sym_post(pt, g, outer, T, B);
-                finished = T.phase == PH_DONE;
+                typename P::Task T = s_park;
+                P::uniformize(T);
+                if (!P::done(T)) P::post(cx, g, outer, T, B);
+                finished = P::done(T);
                 if (finished) {
                     int st = 0;
-                    const double val = sym_result(pt, T, st);
+                    const double val = P::result(cx, T, st);
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
                         if (a.status) a.status[own_i * 8 + own_slot] = st;
@@ -526,7 +597,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
                     double norm;
                     const size_t hi = (size_t) bcast_u64(bget(&src->point));
                     const int hs = __builtin_amdgcn_readfirstlane(bget(&src->slot));
-                    load_context<KIND>(a, hi, hs, pt, d, norm);
+                    P::load(a, hi, hs, cx, norm);
                     ctx_loaded = true;
                     if (counted_idle) {
                         if (lane == 0) __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -548,7 +619,7 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
             int st = 0;
             const unsigned long long e0 = wall_clock64();
             RIM_PROF_T(t_req);
-            const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, st);
+            const double val = P::eval(cx, g, inner, &s_qpark, n, lb, st);
             RIM_PROF_ADD(9, t_req);
             eval_ticks += wall_clock64() - e0;
             if (shared) {
@@ -608,9 +679,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
         }
         __syncthreads();
         {
-            TaskState T = s_park;
-            task_uniformize(T);
-            sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
+            typename P::Task T = s_park;
+            P::uniformize(T);
+            P::consume(cx, g, outer, T, B, gval, uni(batch_status));
             __syncthreads();
             if (lane == 0) s_park = T;
             __syncthreads();
@@ -623,9 +694,9 @@ __global__ __launch_bounds__(64, RIM_SYM_WAVES) void symphony_kernel(SymArgs a)
     if (threadIdx.x < 32) g_rim_prof[(size_t) blockIdx.x * 32 + threadIdx.x] += rim_prof_lds[threadIdx.x];
 #endif
     if (g.lane == 0) {
-        atomicAdd(a.queue + 1, s_qpark.ctr.samples);
-        atomicAdd(a.queue + 2, s_qpark.ctr.steps);
-        atomicAdd(a.queue + 3, s_qpark.ctr.inner_qags);
+        atomicAdd(queue + 1, s_qpark.ctr.samples);
+        atomicAdd(queue + 2, s_qpark.ctr.steps);
+        atomicAdd(queue + 3, s_qpark.ctr.inner_qags);
         atomicAdd(a.queue + 8, n_shared_batches);
         atomicAdd(a.queue + 9, n_helper_reqs);
         atomicAdd(a.queue + 10, n_owner_shared_reqs);
@@ -647,79 +718,6 @@ __global__ void board_init_kernel(unsigned *flags, unsigned active)
 // ------------------------------------------------------------------------------
 // heyvaerts (Faraday rho_Q = slot 6, rho_V = slot 7)
 // ------------------------------------------------------------------------------
-
-template <int KIND>
-__global__ __launch_bounds__(64) void heyvaerts_kernel(SymArgs a)
-{
-    __shared__ double s_tab[96];
-    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
-    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
-    __shared__ HeyTask s_park;
-    const GKLane g = gk_lane_init(s_tab);
-    double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
-    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
-    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
-    __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
-
-    HeyConsts hc = hey_consts();
-    hc.g_p23 = uni(hc.g_p23); hc.g_m23 = uni(hc.g_m23); hc.g_p13 = uni(hc.g_p13); hc.g_m13 = uni(hc.g_m13);
-
-    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
-    for (;;) {
-        const unsigned long long t = wave_next_task(a.queue + 4, g.lane);
-        if (t >= ntasks) break;
-        const size_t seq = (size_t) (t / (unsigned) a.nslots);
-        const size_t i = a.perm ? (size_t) a.perm[seq] : seq;
-        const int slot = a.slot[(int) (t % (unsigned) a.nslots)];
-
-        HeyPoint pt;
-        pt.s = uni(a.s[i]);
-        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
-        pt.sin_th = uni(pt.sin_th);
-        pt.cos_th = uni(pt.cos_th);
-        pt.sigma0 = uni(pt.s * pt.sin_th);
-        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
-        pt.stokes = uni(c_slot_stokes[slot]);
-
-        DistParams d;
-        load_params<KIND>(a.pp, i, d);
-        const double norm = uni(a.norm[i]);
-        dist_prepare<KIND>(d, norm);
-#pragma unroll
-        for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
-        d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
-        d.inv_kappa_width = uni(d.inv_kappa_width);
-        d.neg_inverse_t = uni(d.neg_inverse_t);
-
-        if (g.lane == 0) {
-            s_qpark.hb = (a.heartbeat && (t | (1ull << 62)) == a.hb_task) ? a.heartbeat : nullptr;
-            if (s_qpark.hb) hb_store(s_qpark.hb + 0, t + 1);
-        }
-        __syncthreads();
-
-        double val;
-        int st = 0;
-        if (!(norm == norm)) {
-            val = RIM_NAN;
-            st = ST_NORM_FAIL | ST_NONFINITE;
-        } else {
-            val = heyvaerts_coefficient<KIND>(pt, d, hc, g, inner, outer, &s_park, &s_qpark, st);
-        }
-        if (g.lane == 0) {
-            a.out[i * 8 + slot] = val;
-            if (a.status) a.status[i * 8 + slot] = st;
-            if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
-        }
-    }
-
-    __syncthreads();
-    if (g.lane == 0) {
-        atomicAdd(a.queue + 5, s_qpark.ctr.samples);
-        atomicAdd(a.queue + 6, s_qpark.ctr.steps);
-        atomicAdd(a.queue + 7, s_qpark.ctr.inner_qags);
-    }
-}
 
 // ------------------------------------------------------------------------------
 // expensive-first task order.  The cost of a point grows with s (about 3x from s < 10 to
@@ -894,8 +892,10 @@ struct rimphony_ctx {
     int32_t *d_status;
     size_t out_cap;
     // HIP events bracketing the most recent symphony_kernel launch
-    hipEvent_t ev_start, ev_stop;
+    hipEvent_t ev_start, ev_stop;   // Symphony launch
     int ev_valid;
+    hipEvent_t ev_fstart, ev_fstop; // Faraday launch
+    int evf_valid;
     // diagnostics: heartbeat words in host-mapped memory
     unsigned long long *hb_host;
     unsigned long long *hb_dev;
@@ -950,7 +950,8 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc(&c->d_queue, 16 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
-    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
+        hipEventCreate(&c->ev_fstart) != hipSuccess || hipEventCreate(&c->ev_fstop) != hipSuccess) {
         (void) hipFree(c->d_queue);
         delete c;
         return RIMPHONY_EHIP;
@@ -974,6 +975,8 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     if (c->hb_host) (void) hipHostFree(c->hb_host);
     (void) hipEventDestroy(c->ev_start);
     (void) hipEventDestroy(c->ev_stop);
+    (void) hipEventDestroy(c->ev_fstart);
+    (void) hipEventDestroy(c->ev_fstop);
     delete c;
 }
 
@@ -1053,13 +1056,13 @@ extern "C" int rimphony_batch_norm_device(rimphony_ctx *c, int kind, size_t n, c
     }
 }
 
-template <int KIND>
-static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
+template <class P>
+static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
     // more waves than tasks on small batches: the surplus waves start as helpers right away
     const unsigned long long want_waves = ntasks > (1ull << 40) ? ntasks : ntasks * 64ull;
-    const unsigned grid = persistent_grid(c, want_waves, 4 * RIM_SYM_WAVES);
+    const unsigned grid = persistent_grid(c, want_waves, 4 * (int) P::WAVES);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
     if (c->board_slots < grid) {
@@ -1077,26 +1080,27 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);
-    HIP_TRY(hipEventRecord(c->ev_start, st));
-    hipLaunchKernelGGL(symphony_kernel<KIND>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
+    HIP_TRY(hipEventRecord(ev_start, st));
+    hipLaunchKernelGGL(coop_kernel<P>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_stop, st));
-    c->ev_valid = 1;
+    HIP_TRY(hipEventRecord(ev_stop, st));
     return RIMPHONY_OK;
+}
+
+template <int KIND>
+static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
+{
+    const int rc = launch_coop<SymphonyProblem<KIND>>(c, a, st, c->ev_start, c->ev_stop);
+    if (rc == RIMPHONY_OK) c->ev_valid = 1;
+    return rc;
 }
 
 template <int KIND>
 static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
-    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
-    const unsigned grid = persistent_grid(c, ntasks, 16);
-    int rc = ensure_spill(c, grid);
-    if (rc) return rc;
-    SymArgs b = a;
-    b.spill = c->d_spill;
-    hipLaunchKernelGGL(heyvaerts_kernel<KIND>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
-    HIP_TRY(hipGetLastError());
-    return RIMPHONY_OK;
+    const int rc = launch_coop<HeyvaertsProblem<KIND>>(c, a, st, c->ev_fstart, c->ev_fstop);
+    if (rc == RIMPHONY_OK) c->evf_valid = 1;
+    return rc;
 }
 
 extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n,
@@ -1233,6 +1237,16 @@ extern "C" int rimphony_last_symphony_ms(rimphony_ctx *c, float *ms)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_last_faraday_ms(rimphony_ctx *c, float *ms)
+{
+    if (!c || !ms) return RIMPHONY_EINVAL;
+    if (!c->evf_valid) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_fstop));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_fstart, c->ev_fstop));
     return RIMPHONY_OK;
 }
 
