@@ -41,7 +41,7 @@ using namespace rim;
 // allocator spills 47 VGPRs to scratch and still wins)
 #ifndef RIM_SYM_WAVES
 #define RIM_SYM_WAVES 6
-#define RIM_HEY_WAVES 2          // heyvaerts: ~200 VGPRs
+#define RIM_HEY_WAVES 5          // heyvaerts: 96 VGPRs (2..6 measured: 869, 708, 653, 626, 646 ms on the 8192-point power-law batch)
 #endif
 
 // ------------------------------------------------------------------------------

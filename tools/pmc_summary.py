@@ -12,6 +12,6 @@ for d in dirs:
             e["counters"][row["Counter_Name"]] = e["counters"].get(row["Counter_Name"], 0.) + float(row["Counter_Value"])
             for c in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"):
                 if c in row: e["launch"][c] = row[c]
-res = [{"kernel": k, "launch": v["launch"], "counters": v["counters"]} for k, v in acc.items() if "symphony" in k]
+res = [{"kernel": k, "launch": v["launch"], "counters": v["counters"]} for k, v in acc.items() if "coop_kernel" in k or "symphony" in k]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
