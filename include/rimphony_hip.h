@@ -172,6 +172,21 @@ int rimphony_gamma_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const
                                          int coeff, int stokes, int negative_lobe, double s, double theta,
                                          size_t count, const double *d_n, double *d_out, void *stream);
 
+/* The reference's own scalar FFI seam, leung-bessel/src/lib.rs:36-42
+ *   extern { fn pkgw_bessel_j(n: c_double, x: c_double) -> c_double; fn pkgw_bessel_dj(...) -> c_double; }
+ * exported under the same names so that crate can link this library in place of leung-bessel/src/bessel.c.
+ * One single-element kernel launch per call on the current HIP device; failure -> NaN (the seam's convention). */
+double pkgw_bessel_j(double n, double x);
+double pkgw_bessel_dj(double n, double x);
+
+/* High-frequency closed-form Faraday coefficients: `high_freq_approximation()` of
+ * PowerLawDistribution (power_law.rs:117-170; d_params = {p, gamma_min, ...}) and of
+ * ThermalJuettnerDistribution (thermal_juettner.rs:78-142; d_params = {T}).  Other kinds: RIMPHONY_EINVAL
+ * (the reference has none).  d_out is [n][2] = {rho_Q, rho_V}, dimensionless.  As in the reference no
+ * check is made that the parameters lie where the approximation is good. */
+int rimphony_highfreq_batch_device(rimphony_ctx *ctx, int dist_kind, size_t n, const double *d_s, const double *d_theta,
+                                   const double *const *d_params, double *d_out, void *stream);
+
 /* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1

@@ -134,6 +134,10 @@ double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negati
 int rimo_batch(int kind, size_t n, const double *s, const double *theta, const double *const *params,
                uint32_t coeff_mask, double *out, rimo_counters *counters, int nthreads);
 
+/* high-frequency closed forms (power_law.rs:133-170, thermal_juettner.rs:94-142): out = {rho_Q, rho_V} */
+int rimo_highfreq(int kind, const double *params, double s, double theta, double out[2]);
+void rimo_bessel_k012(double x, double k[3]);
+
 int rimo_batch_norm(int kind, size_t n, const double *const *params, double *norm);
 
 /* QAG self-test on integrands built from + - * / sqrt only (see include/rimphony_hip.h) */

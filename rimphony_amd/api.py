@@ -125,6 +125,19 @@ class Context:
             return out.cpu().numpy(), st.cpu().numpy()
         return out.cpu().numpy()
 
+    def highfreq_batch(self, kind, s, theta, params):
+        """High-frequency closed forms (power law / thermal only): host arrays in, [n, 2] = {rho_Q, rho_V} out."""
+        ds, dth = self._as_dev(s), self._as_dev(theta)
+        dp = [self._as_dev(p) for p in params]
+        n = ds.numel()
+        out = torch.empty((n, 2), dtype=torch.float64, device=self._dev())
+        pp = (ctypes.c_void_p * len(dp))(*[ctypes.c_void_p(p.data_ptr()) for p in dp])
+        capi.check(self.lib.rimphony_highfreq_batch_device(
+            self.handle, kind, n, ctypes.c_void_p(ds.data_ptr()), ctypes.c_void_p(dth.data_ptr()), pp,
+            ctypes.c_void_p(out.data_ptr()), self._stream()), "rimphony_highfreq_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def last_work(self):
         w = capi.Work()
         capi.check(self.lib.rimphony_last_work(self.handle, ctypes.byref(w)), "rimphony_last_work")
@@ -265,6 +278,25 @@ class FullSynchrotronCalculator:
         return v * scale
 
 
+class HighFrequencyApproximation:
+    """SynchrotronCalculator over the closed-form high-frequency approximations
+    (power_law.rs:131-170, thermal_juettner.rs:92-142): (Faraday, Q) and (Faraday, V); anything else is NaN."""
+
+    def __init__(self, kind, params, ctx=None):
+        if kind not in (POWER_LAW, THERMAL_JUETTNER):
+            raise ValueError("the reference defines high-frequency approximations for power_law and thermal_juettner only")
+        self.kind = kind
+        self.params = [float(p) for p in params]
+        self.ctx = ctx or default_context()
+
+    def compute_dimensionless(self, coeff, stokes, s, theta):
+        if int(coeff) != int(Coefficient.Faraday) or int(stokes) == int(Stokes.I):
+            return float("nan")
+        out = self.ctx.highfreq_batch(self.kind, np.array([s], dtype=np.float64), np.array([theta], dtype=np.float64),
+                                      [np.array([p], dtype=np.float64) for p in self.params])
+        return float(out[0, 0 if int(stokes) == int(Stokes.Q) else 1])
+
+
 class PowerLawDistribution:
     def __init__(self, p):
         self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff = float(p), 1.0, 1e12, 1e10
@@ -276,6 +308,9 @@ class PowerLawDistribution:
     def full_calculation(self, ctx=None):
         return FullSynchrotronCalculator(POWER_LAW, [self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
 
+    def high_freq_approximation(self, ctx=None):
+        return HighFrequencyApproximation(POWER_LAW, [self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
+
 
 class ThermalJuettnerDistribution:
     def __init__(self, t):
@@ -283,6 +318,9 @@ class ThermalJuettnerDistribution:
 
     def full_calculation(self, ctx=None):
         return FullSynchrotronCalculator(THERMAL_JUETTNER, [self.t], ctx)
+
+    def high_freq_approximation(self, ctx=None):
+        return HighFrequencyApproximation(THERMAL_JUETTNER, [self.t], ctx)
 
 
 class PitchyPowerLawDistribution:

@@ -16,9 +16,11 @@
 #include <new>
 #include <vector>
 
+#include <mutex>
 #include "../../include/rimphony_hip.h"
 #include "symphony_wave.h"
 #include "heyvaerts_wave.h"
+#include "highfreq.h"
 
 using namespace rim;
 
@@ -1317,6 +1319,41 @@ extern "C" int rimphony_bessel_batch_device(rimphony_ctx *c, size_t count, const
     return RIMPHONY_OK;
 }
 
+// ---- the reference's scalar FFI seam (leung-bessel/src/lib.rs:36-42) -----------------------
+// `extern { fn pkgw_bessel_j(n: c_double, x: c_double) -> c_double; fn pkgw_bessel_dj(..) }`: the same
+// two C symbols, so the reference's leung-bessel crate can link this library instead of bessel.c.
+// Each call is one single-element kernel launch on the current device (tens of microseconds):
+// correct drop-in, not a fast path -- use rimphony_bessel_batch_device for arrays.  Errors (no GPU,
+// HIP failure) follow the seam's convention: NaN.
+static int scalar_bessel(double n, double x, double *j, double *dj)
+{
+    static std::mutex mu;
+    static double *d_buf = nullptr;      // {n, x, j, dj}
+    std::lock_guard<std::mutex> lock(mu);
+    if (!d_buf && hipMalloc(&d_buf, 4 * sizeof(double)) != hipSuccess) { d_buf = nullptr; return RIMPHONY_EHIP; }
+    const double in[2] = { n, x };
+    if (hipMemcpy(d_buf, in, sizeof in, hipMemcpyHostToDevice) != hipSuccess) return RIMPHONY_EHIP;
+    hipLaunchKernelGGL(bessel_kernel, dim3(1), dim3(256), 0, (hipStream_t) 0, (size_t) 1, d_buf, d_buf + 1, d_buf + 2, d_buf + 3);
+    if (hipGetLastError() != hipSuccess) return RIMPHONY_EHIP;
+    double out[2];
+    if (hipMemcpy(out, d_buf + 2, sizeof out, hipMemcpyDeviceToHost) != hipSuccess) return RIMPHONY_EHIP;
+    *j = out[0];
+    *dj = out[1];
+    return RIMPHONY_OK;
+}
+
+extern "C" double pkgw_bessel_j(double n, double x)
+{
+    double j, dj;
+    return scalar_bessel(n, x, &j, &dj) == RIMPHONY_OK ? j : RIM_NAN;
+}
+
+extern "C" double pkgw_bessel_dj(double n, double x)
+{
+    double j, dj;
+    return scalar_bessel(n, x, &j, &dj) == RIMPHONY_OK ? dj : RIM_NAN;
+}
+
 static int fill_point_args(int kind, const double *params, int coeff, int stokes, int negative_lobe,
                            double s, double theta, PointArgs &pa)
 {
@@ -1413,6 +1450,40 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+// ---- high-frequency closed forms ---------------------------------------------
+__global__ void highfreq_kernel(int kind, size_t n, const double *s, const double *theta, const double *p0,
+                                const double *p1, double *out)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double sn, cs;
+    rim_sincos(theta[i], &sn, &cs);
+    double q, v;
+    if (kind == RIMPHONY_POWER_LAW) {
+        q = rim_hf_powerlaw_faraday_q(p0[i], p1[i], s[i], sn);
+        v = rim_hf_powerlaw_faraday_v(p0[i], p1[i], s[i], sn);
+    } else {
+        rim_hf_thermal_faraday(p0[i], s[i], sn, cs, &q, &v);
+    }
+    out[2 * i] = q;
+    out[2 * i + 1] = v;
+}
+
+extern "C" int rimphony_highfreq_batch_device(rimphony_ctx *c, int kind, size_t n, const double *d_s, const double *d_theta,
+                                              const double *const *d_params, double *d_out, void *stream)
+{
+    if (!c) return RIMPHONY_EINVAL;
+    if (kind != RIMPHONY_POWER_LAW && kind != RIMPHONY_THERMAL_JUETTNER) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;
+    if (!d_s || !d_theta || !d_params || !d_out || !d_params[0]) return RIMPHONY_EINVAL;
+    if (kind == RIMPHONY_POWER_LAW && !d_params[1]) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(highfreq_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, kind, n,
+                       d_s, d_theta, d_params[0], kind == RIMPHONY_POWER_LAW ? d_params[1] : nullptr, d_out);
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
 }

@@ -65,6 +65,8 @@ def load(flavour="det"):
     L.rimo_deriv_central.restype = c_int
     L.rimo_deriv_central.argtypes = [FN, c_void_p, c_double, c_double, dp, dp]
     L.rimo_hyperg_2F1_at_1.restype = c_double; L.rimo_hyperg_2F1_at_1.argtypes = [c_double] * 3
+    L.rimo_highfreq.restype = c_int; L.rimo_highfreq.argtypes = [c_int, dp, c_double, c_double, dp]
+    L.rimo_bessel_k012.restype = None; L.rimo_bessel_k012.argtypes = [c_double, dp]
     L.rimo_build_flavour.restype = ctypes.c_char_p
     _cache[name] = L
     return L
@@ -116,3 +118,18 @@ def qag_selftest(L, family, p0, p1, a, b, epsabs, epsrel, limit):
     st = L.rimo_qag_selftest(int(family), p0, p1, a, b, epsabs, epsrel, limit, ctypes.byref(r), ctypes.byref(e),
                              ctypes.byref(sz))
     return st, r.value, e.value, sz.value
+
+
+def highfreq(L, kind, params, s, theta):
+    """{rho_Q, rho_V} of the high-frequency closed forms (power law kind 0 / thermal kind 1)."""
+    par = (c_double * len(params))(*[float(p) for p in params])
+    out = (c_double * 2)()
+    rc = L.rimo_highfreq(kind, par, float(s), float(theta), out)
+    assert rc == 0
+    return out[0], out[1]
+
+
+def bessel_k012(L, x):
+    k = (c_double * 3)()
+    L.rimo_bessel_k012(float(x), k)
+    return k[0], k[1], k[2]

@@ -57,6 +57,22 @@ def test_bessel_bit_exact(gpu_ctx, oracle):
     report_mismatch("bessel_dj", dj, rdj, lambda i: (n[i], x[i]))
 
 
+def test_scalar_bessel_seam(gpu_ctx, oracle):
+    """pkgw_bessel_j / pkgw_bessel_dj, the reference's own FFI seam (leung-bessel/src/lib.rs:36-42), as exported
+    by the library: same bits as the batch entry point and the oracle, NaN conventions included."""
+    from rimphony_amd import capi
+    lib = capi.load()
+    for n, x in [(2., 1.5), (29., 28.5), (100., 99.), (1e6, 999000.), (30.5, 10.), (12.5, 3.), (50., 50.), (40., -1.)]:
+        rj, rdj = oracle.rimo_bessel_j(n, x), oracle.rimo_bessel_dj(n, x)
+        j, dj = lib.pkgw_bessel_j(n, x), lib.pkgw_bessel_dj(n, x)
+        assert (j == rj or (math.isnan(j) and math.isnan(rj))), (n, x, j, rj)
+        assert (dj == rdj or (math.isnan(dj) and math.isnan(rdj))), (n, x, dj, rdj)
+    # the reference's own smoke values (leung-bessel/src/lib.rs:82-86, assert_approx_eq at 1e-6)
+    assert abs(lib.pkgw_bessel_j(0., 0.) - 1.) < 1e-6
+    assert abs(lib.pkgw_bessel_j(5., 5.) - 0.2611405) < 1e-6
+    assert abs(lib.pkgw_bessel_j(0., 17.) + 0.1698543) < 1e-6
+
+
 def _kind_params(rng, kind):
     if kind == 0:
         return [rng.uniform(1.5, 4), float(np.exp(rng.uniform(0, math.log(30)))), 1e12, 1e10]

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_exports_every_declared_symbol():
     _build.build_hip()
     hdr = open(os.path.join(ROOT, "include", "rimphony_hip.h")).read()
-    names = set(re.findall(r"\b(rimphony_[a-z0-9_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b((?:rimphony|pkgw_bessel)_[a-z0-9_]+)\s*\(", hdr))
     names -= {"rimphony_ctx"}
     assert len(names) >= 13
     lib = ctypes.CDLL(os.path.join(ROOT, "rimphony_amd", "librimphony_hip.so"))
