@@ -16,7 +16,7 @@ compute) and the output table is gathered to rank 0 with one RCCL gather inside
 the timed region.  Inputs are resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0).  `value` = parameter points per second, whole job.
-`roofline` is for the dominant kernel (symphony_kernel): algorithmic fp64 flops
+`roofline` is for the dominant kernel (coop_kernel<SymphonyProblem<0>>, "symphony kernel" below): algorithmic fp64 flops
 (device-counted integrand samples x the per-sample figure of DESIGN.md) over
 its HIP-event-measured duration, against the fp64 vector peak -- the path is
 VALU-bound, not HBM- or MFMA-bound, hence "bound": "valu_fp64".
@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 # (Debye 21 %, Meissel-1 73 %, blend 5 %, integer order 1 %).
 FLOPS_PER_SAMPLE = 720.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
-# HBM-side bytes of symphony_kernel measured with rocprofv3 PMC (FETCH_SIZE and WRITE_SIZE, separate passes,
+# HBM-side bytes of the symphony kernel measured with rocprofv3 PMC (FETCH_SIZE and WRITE_SIZE, separate passes,
 # KB -> bytes; narrow accesses, so the gfx950 "wide read" doubling does not apply) on one 65536-row launch of
 # this table: profiles/r1_final_pmc_symphony_65536pts.json.  Nearly all of it is scratch (register spill)
 # traffic; it scales with the sample count, hence the per-sample figure.  Algorithmic bytes are ~150 B/point.
@@ -139,7 +139,7 @@ def main():
             "bound": "valu_fp64", "achieved": round(achieved, 4), "peak": FP64_VECTOR_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / FP64_VECTOR_PEAK_TFLOPS, 5),
             "traffic": round(PMC_BYTES_PER_SAMPLE * avg_samples),
-            "kernel": "symphony_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
+            "kernel": "coop_kernel<SymphonyProblem<0>>", "kernel_ms": round(avg_kernel_s * 1e3, 3),
             "samples_per_launch": avg_samples, "flops_per_sample": FLOPS_PER_SAMPLE,
             "traffic_note": "bytes/launch = PMC bytes/sample (profiles/r1_final_pmc_symphony_65536pts.json) x samples",
         }

@@ -2,7 +2,9 @@
 //
 // Kernels (one 64-lane wavefront per workgroup; each wave owns its LDS):
 //   norm_kernel<KIND>      full_calculation(): per-point normalisation integral
-//   symphony_kernel<KIND>  (point, coefficient) tasks pulled from an atomic queue
+//   coop_kernel<P>         (point, coefficient) tasks pulled from an atomic queue, with a cooperative tail;
+//                          P = SymphonyProblem<KIND> (j, alpha) or HeyvaertsProblem<KIND> (rho_Q, rho_V)
+//   highfreq_kernel        closed-form high-frequency rho_Q, rho_V
 //   bessel_kernel, integrand_kernel, gamma_integral_kernel, qag_selftest_kernel
 //                          unit seams used by the parity tests
 //
@@ -893,7 +895,7 @@ struct rimphony_ctx {
     double *d_out;
     int32_t *d_status;
     size_t out_cap;
-    // HIP events bracketing the most recent symphony_kernel launch
+    // HIP events bracketing the most recent Symphony / Faraday launch
     hipEvent_t ev_start, ev_stop;   // Symphony launch
     int ev_valid;
     hipEvent_t ev_fstart, ev_fstop; // Faraday launch
