@@ -56,3 +56,47 @@ def test_driver_on_gpu(tmp_path, gpu_ctx):
     lines = out.read_text().strip().split("\n")
     assert lines[0] == crank_out.HEADER_PITCHYKAPPA and len(lines) == 7
     assert all(len(ln.split("\t")) == 14 for ln in lines[1:])
+
+
+def test_demo_powerlaw_and_all8_text():
+    """Text layout of the two remaining reference drivers (examples/demo-powerlaw.rs:127-175,
+    examples/all-pitchykappa-cgs.rs:101-132) with a stand-in compute (no GPU here)."""
+    from rimphony_amd import drivers
+    seen = {}
+
+    def fake(kind, s, th, params):
+        seen["n"] = len(s)
+        seen["p"] = params[0].copy()
+        return np.tile(np.arange(1., 9.) * 1e-20, (len(s), 1))
+
+    lines = drivers.demo_powerlaw_lines(fake)
+    assert lines[0].split("\t")[:4] == ["s(lin)", "theta(lin)", "p(lin)", "d(meta)"] and len(lines) == 65
+    assert seen["n"] == 64 and seen["p"][0] == 3. and abs(seen["p"][-1] - 2.5) < 1e-15
+    first = lines[1].split("\t")
+    assert first[0] == "1.0000000000000000e2" and first[1] == "5.0000000000000000e-1" and first[7] == "9.9999999999999995e-21"
+    last = lines[-1].split("\t")
+    assert last[0] == "9.0000000000000000e1" and last[3] == "3.0000000000000000e10" and len(last) == 15
+
+    class Calc:
+        def compute_all_cgs(self, nu, b, n_e, theta):
+            return np.arange(1., 9.) * 1.5
+
+    out = drivers.all_pitchykappa_cgs_lines(lambda dist: Calc(), 1e9, 100., 1., 0.7, 4., 10., 1.)
+    assert out[0] == "    j_I: 1.500000000000000000e0" and out[7].startswith("  rho_V: 1.2") and len(out) == 8
+
+
+@pytest.mark.gpu
+def test_demo_and_all8_on_gpu(gpu_ctx):
+    """The demo's 64 rows and the 8 cgs lines equal the per-point calculator interface (bitwise: the results do
+    not depend on batch composition) and carry no NaN."""
+    from rimphony_amd import api, drivers
+    lines = drivers.demo_powerlaw_lines(lambda kind, s, th, params: gpu_ctx.compute_batch(kind, s, th, params, api.SLOTS_ALL))
+    assert len(lines) == 65
+    rows = np.array([[float(c) for c in ln.split("\t")] for ln in lines[1:]])
+    assert np.isfinite(rows).all()
+    calc = api.PowerLawDistribution(rows[5, 2]).gamma_limits(1., 1e12, 1e10).full_calculation(gpu_ctx)
+    one = calc.compute_all_dimensionless(rows[5, 0], rows[5, 1])
+    assert [drivers.rust_e16(x) for x in one] == lines[6].split("\t")[7:]
+    out = drivers.all_pitchykappa_cgs_lines(lambda dist: dist.full_calculation(gpu_ctx), 1e9, 100., 1., 0.7, 4., 10., 1.)
+    vals = [float(ln.split(": ")[1]) for ln in out]
+    assert len(vals) == 8 and all(math.isfinite(v) for v in vals) and vals[0] > 0 and vals[1] > 0
