@@ -321,9 +321,11 @@ struct SymphonyProblem {
     static __device__ __forceinline__ bool done(const Task &T) { return T.phase == PH_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
     { sym_post(c.pt, g, outer, T, B); }
-    static __device__ __forceinline__ double eval(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
-                                                  double x, int tag, int &st)
-    { return sym_eval_request<KIND>(c.pt, c.d, g, inner, qp, x, tag, st); }
+    // one or two requests ((x1, tag1) only if have1): two gamma-integrals share their first rule application
+    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+                                                 double x0, int tag0, double x1, int tag1, bool have1,
+                                                 double &v0, int &st0, double &v1, int &st1)
+    { sym_eval_pair<KIND>(c.pt, c.d, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
                                                    const SymBatch &B, double gval, int bst)
     { sym_consume(c.pt, g, outer, T, B, gval, bst); }
@@ -364,9 +366,19 @@ struct HeyvaertsProblem {
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
     { hey_post(c.pt, g, outer, T, B); }
-    static __device__ __forceinline__ double eval(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
-                                                  double x, int tag, int &st)
-    { return hey_eval_request<KIND>(c.pt, c.d, c.hc, g, inner, qp, x, tag, st); }
+    // the two requests are evaluated one after the other, in one inlined loop (no pairing on this path yet)
+    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+                                                 double x0, int tag0, double x1, int tag1, bool have1,
+                                                 double &v0, int &st0, double &v1, int &st1)
+    {
+        v0 = 0.; v1 = 0.;
+#pragma nounroll
+        for (int r = 0; r < (have1 ? 2 : 1); r++) {
+            int st = 0;
+            const double v = hey_eval_request<KIND>(c.pt, c.d, c.hc, g, inner, qp, r ? x1 : x0, r ? tag1 : tag0, st);
+            if (r) { v1 = v; st1 |= st; } else { v0 = v; st0 |= st; }
+        }
+    }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
                                                    const SymBatch &B, double gval, int bst)
     { hey_consume(c.pt, g, outer, T, B, gval, bst); }
@@ -616,14 +628,25 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 n = readlane_d(B.req_n, kl);
                 lb = wv_readlane(B.req_lobe, kl);
             }
+            // a wave working through its own batch starts two requests together (P::eval2)
+            int k2 = -1;
+            double n2 = n;
+            int lb2 = lb;
+            if (!shared && local_mask) {
+                k2 = __builtin_ffsll((long long) local_mask) - 1;
+                local_mask &= local_mask - 1;
+                n2 = readlane_d(B.req_n, k2);
+                lb2 = wv_readlane(B.req_lobe, k2);
+            }
             if (lane == 0 && s_qpark.hb) {
                 hb_store(s_qpark.hb + 8, (unsigned long long) k);
                 hb_store(s_qpark.hb + 9, rim_bits(n));
             }
-            int st = 0;
+            int st = 0, st2 = 0;
+            double val, val2;
             const unsigned long long e0 = wall_clock64();
             RIM_PROF_T(t_req);
-            const double val = P::eval(cx, g, inner, &s_qpark, n, lb, st);
+            P::eval2(cx, g, inner, &s_qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
             RIM_PROF_ADD(9, t_req);
             eval_ticks += wall_clock64() - e0;
             if (shared) {
@@ -635,7 +658,8 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 }
             } else {
                 if (lane == k) gval = val;
-                batch_status |= st;
+                if (lane == k2) gval = val2;
+                batch_status |= st | st2;
             }
         }
         if (helper) {

@@ -257,37 +257,134 @@ __device__ __forceinline__ bool sym_post(const SymPoint &pt, const GKLane &g, co
     return true;
 }
 
-// One request: gamma_integral(n) for the given lobe (symphony.rs:312-389).  THE integrand site.
+// One or two requests: gamma_integral(n) for the given lobe (symphony.rs:312-389).  THE integrand site.
+//
+// The first rule application of a gamma-integral uses 31 lanes.  Two requests are therefore started
+// together: lanes 0..30 apply the rule to request 0, lanes 32..62 to request 1 (each half-wave also
+// computes its own request's order data and limits), then request 0's bisections run to the end on
+// the whole wave, then request 1 continues from its parked first-rule result.  Every request sees
+// exactly the arithmetic of a solo evaluation (a half-wave's rule sums never involve the other half).
+template <int KIND>
+__device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistParams &dist, const GKLane &g,
+                                              const IStore &inner, QagPark *qpark,
+                                              double n0, int lobe0, double n1, int lobe1, bool have1,
+                                              double &val0, int &st0, double &val1, int &st1)
+{
+    const int lane = g.lane;
+    RIM_PROF_T(t_setup);
+    // ---- setup: every lane computes the data of its half's request, lanes 0 and 32 file them in LDS ----
+    const bool second = g.half != 0 && have1;
+    const double n_l = second ? n1 : n0;
+    LeungOrder ord_tmp[2];
+    const SymOrder so_l = sym_order(n_l, ord_tmp);
+    const GammaLimits L = gamma_limits(pt, n_l, second ? lobe1 : lobe0);
+    wv_sync();                       // nobody is still reading the previous requests' records
+    if (lane == 0) { qpark->ord[0] = ord_tmp[0]; qpark->ord[1] = ord_tmp[1]; }
+    if (lane == 32) { qpark->ord[2] = ord_tmp[0]; qpark->ord[3] = ord_tmp[1]; }
+    wv_sync();
+    const double a0 = readlane_d(L.g0, 0), b0 = readlane_d(L.g1, 0);
+    const double a1 = readlane_d(L.g0, 32), b1 = readlane_d(L.g1, 32);
+    const int fl_l = (so_l.small ? 1 : 0) | (so_l.np1_small ? 2 : 0) | (so_l.dj_nan ? 4 : 0);
+    const int fl0 = wv_readlane(fl_l, 0), fl1 = wv_readlane(fl_l, 32);
+    n0 = uni(n0); n1 = uni(n1);
+    RIM_PROF_ADD(7, t_setup);
+
+    QagState q;
+    qag_begin(q, 0., 1e-3, 5000);
+    int phase = 0;                   // 0: the joint first rule application, 1: bisections of request `cur`
+    int cur = 0;
+    double fb0 = 0., fb1 = 0., fb2 = 0., fb3 = 0.;
+    val0 = 0.; val1 = 0.;
+    int s0 = 0, s1 = 0;
+
+    for (;;) {
+        double la, lb;
+        bool active, slot1;
+        if (phase == 0) {
+            la = L.g0; lb = L.g1;
+            slot1 = second;
+            active = g.node && (g.half == 0 || have1);
+        } else {
+            RIM_PROF_T(t_pick);
+            qag_pick(q, inner, lane);
+            RIM_PROF_ADD(13, t_pick);
+            la = g.half ? q.a2 : q.a1;
+            lb = g.half ? q.b2 : q.b1;
+            slot1 = cur != 0;
+            active = g.node;
+        }
+        SymOrder so;
+        const int fl = slot1 ? fl1 : fl0;
+        so.n = slot1 ? n1 : n0;
+        so.small = (fl & 1) != 0; so.np1_small = (fl & 2) != 0; so.dj_nan = (fl & 4) != 0;
+        so.o = qpark->ord + (slot1 ? 2 : 0);
+        const double hl = 0.5 * (lb - la);
+        const double x = 0.5 * (la + lb) + hl * g.t;
+        if (lane == 0) {
+            qpark->q = q;
+            qpark->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
+            qpark->ctr.steps += 1;
+            if (qpark->hb) {
+                hb_store(qpark->hb + 3, qpark->ctr.steps);
+                hb_store(qpark->hb + 4, (unsigned long long) q.iteration);
+            }
+        }
+        RIM_PROF_T(t_int);
+        const double fv = active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
+        RIM_PROF_ADD(1, t_int);
+        RIM_PROF_T(t_unpark);
+        wv_sync();
+        q = qpark->q;
+        qag_uniformize(q);
+        RIM_PROF_ADD(14, t_unpark);
+
+        RIM_PROF_T(t_gk);
+        const GKRes r = wave_gk31(fv, hl, g);
+        RIM_PROF_ADD(11, t_gk);
+        bool finished;
+        if (phase == 0) {
+            fb0 = readlane_d(r.result, 32); fb1 = readlane_d(r.abserr, 32);
+            fb2 = readlane_d(r.resabs, 32); fb3 = readlane_d(r.resasc, 32);
+            finished = qag_after_first(q, inner, lane, a0, b0, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
+                                       readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
+            phase = 1;
+        } else {
+            RIM_PROF_T(t_ab);
+            finished = qag_after_bisect(q, inner, lane,
+                                        readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
+                                        readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+            RIM_PROF_ADD(12, t_ab);
+        }
+        if (!finished) continue;
+
+        // request `cur` is complete
+        for (;;) {
+            double v = uni(q.result);
+            int st = 0;
+            if (uni(q.status) != QAG_SUCCESS) {
+                v = RIM_NAN;
+                st |= ST_INNER_FAIL;
+                if (q.status == QAG_ESTORE) st |= ST_STORE_FULL;
+            }
+            if (lane == 0) qpark->ctr.inner_qags += 1;
+            if (cur == 0) { val0 = v; s0 = st; } else { val1 = v; s1 = st; }
+            if (cur != 0 || !have1) { st0 |= s0; st1 |= s1; return; }
+            // request 1 continues from its parked first-rule result
+            cur = 1;
+            qag_begin(q, 0., 1e-3, 5000);
+            if (!qag_after_first(q, inner, lane, a1, b1, fb0, fb1, fb2, fb3)) break;
+        }
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ double sym_eval_request(const SymPoint &pt, const DistParams &dist, const GKLane &g,
                                                    const IStore &inner, QagPark *qpark, double n, int lobe, int &st)
 {
-    RIM_PROF_T(t_setup);
-    // every lane computes the (uniform) order data; lane 0 files it in LDS for the integrand
-    LeungOrder ord_tmp[2];
-    SymOrder so = sym_order(n, ord_tmp);
-    wv_sync();                       // nobody is still reading the previous request's records
-    if (g.lane == 0) { qpark->ord[0] = ord_tmp[0]; qpark->ord[1] = ord_tmp[1]; }
-    wv_sync();
-    so.n = uni(so.n); so.small = uni(so.small); so.np1_small = uni(so.np1_small); so.dj_nan = uni(so.dj_nan);
-    so.o = qpark->ord;
-    GammaLimits L = gamma_limits(pt, n, lobe);
-    L.g0 = uni(L.g0);
-    L.g1 = uni(L.g1);
-    RIM_PROF_ADD(7, t_setup);
-    auto f = [&](double x, bool active) -> double {
-        return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
-    };
-    QagState iq;
-    wave_qag(f, g, inner, L.g0, L.g1, 0., 1e-3, 5000, iq, qpark);
-    if (g.lane == 0) qpark->ctr.inner_qags += 1;
-    double val = uni(iq.result);
-    if (uni(iq.status) != QAG_SUCCESS) {
-        val = RIM_NAN;
-        st |= ST_INNER_FAIL;
-        if (iq.status == QAG_ESTORE) st |= ST_STORE_FULL;
-    }
-    return val;
+    double v0, v1;
+    int s1 = 0;
+    sym_eval_pair<KIND>(pt, dist, g, inner, qpark, n, lobe, n, lobe, false, v0, st, v1, s1);
+    return v0;
 }
 
 // Continuation of the phase that posted B, given the results (lane k holds the value of request k).
@@ -425,8 +522,21 @@ __device__ __forceinline__ double symphony_coefficient(const SymPoint &pt, const
             mask &= mask - 1;
             const double n = readlane_d(B.req_n, k);
             const int lb = wv_readlane(B.req_lobe, k);
-            const double val = sym_eval_request<KIND>(pt, dist, g, inner, qpark, n, lb, batch_status);
+            int k2 = -1;
+            double n2 = n;
+            int lb2 = lb;
+            if (mask) {
+                k2 = __builtin_ffsll((long long) mask) - 1;
+                mask &= mask - 1;
+                n2 = readlane_d(B.req_n, k2);
+                lb2 = wv_readlane(B.req_lobe, k2);
+            }
+            double val, val2;
+            int st = 0, st2 = 0;
+            sym_eval_pair<KIND>(pt, dist, g, inner, qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
+            batch_status |= st | st2;
             if (lane == k) gval = val;
+            if (lane == k2) gval = val2;
         }
         wv_sync();
         T = *park;

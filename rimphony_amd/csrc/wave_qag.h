@@ -401,7 +401,7 @@ struct WaveCounters {
 // integrand runs, so that the integrand has the vector register file to itself.
 struct QagPark {
     QagState q;
-    LeungOrder ord[2];        // order records of the gamma-integral being evaluated (dev_symphony.h: SymOrder)
+    LeungOrder ord[4];        // order records (n, n + 1) of the one or two gamma-integrals in flight (SymOrder)
     WaveCounters ctr;
     unsigned long long *hb;   // optional heartbeat words in host-mapped memory (diagnostics), else null
 };
