@@ -135,43 +135,79 @@ __device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, co
     return true;
 }
 
-// One request: the inner integral at outer abscissa u (heyvaerts.rs:213-250 non-resonant, 262-296 quasi-resonant).
+// One or two requests: the inner integral at outer abscissa u (heyvaerts.rs:213-250 non-resonant, 262-296
+// quasi-resonant).  THE site of the inner QAG and the integrand.  Two requests share their first rule
+// application (wave_qag_pair); a request whose sigma range is empty contributes 0 without a quadrature
+// (heyvaerts.rs:224-226), and the other one then runs alone.
+template <int KIND>
+__device__ __forceinline__ void hey_eval_pair(const HeyPoint &pt, const DistParams &dist, const HeyConsts &hc,
+                                              const GKLane &g, const IStore &inner, QagPark *qpark,
+                                              double u0, int qr0, double u1, int qr1, bool have1,
+                                              double &val0, int &st0, double &val1, int &st1)
+{
+    // every lane sets up the request of its half
+    const bool sec = g.half != 0 && have1;
+    const double u_l = sec ? u1 : u0;
+    const bool qr_l = (sec ? qr1 : qr0) != 0;
+    double lo_l, hi_l;
+    bool empty_l = false;
+    if (!qr_l) {
+        const double sigma_min = rim_sqrt(u_l * u_l + pt.sigma0_sq);
+        const double sigma_max = RIM_INVERSE_SQRT_3 * rim_pow(sigma_min, 1.5);
+        empty_l = sigma_max <= sigma_min;
+        lo_l = sigma_min; hi_l = sigma_max;
+    } else {
+        const double pomega_max_phys = rim_sqrt(RIM_THREE_TWO_THIRDS * rim_pow(u_l, 4. / 3.) - pt.sigma0_sq);
+        const double pomega_max_qr = rim_sqrt(u_l * u_l - pt.sigma0_sq);
+        const double pomega_max = rust_min(pomega_max_phys, pomega_max_qr);
+        lo_l = -pomega_max; hi_l = pomega_max;
+    }
+    const double a0 = readlane_d(lo_l, 0), b0 = readlane_d(hi_l, 0);
+    const double a1 = readlane_d(lo_l, 32), b1 = readlane_d(hi_l, 32);
+    const bool todo0 = wv_readlane(empty_l ? 1 : 0, 0) == 0;
+    const bool todo1 = have1 && wv_readlane(empty_l ? 1 : 0, 32) == 0;
+    u0 = uni(u0); u1 = uni(u1);
+    const bool q0 = uni(qr0) != 0, q1 = uni(qr1) != 0;
+    val0 = 0.; val1 = 0.;
+    if (!todo0 && !todo1) return;
+
+    auto f = [&](double v, bool active, bool second) -> double {
+        return active ? hey_element<KIND>(pt, dist, hc, second ? q1 : q0, second ? u1 : u0, v) : 0.;
+    };
+    // both: one joint run.  Only one of them: it runs as "integral 0" (flip maps it to its own data).
+    const bool both = todo0 && todo1;
+    const bool flip = !todo0;
+    double r0, r1;
+    int qs0, qs1;
+    wave_qag_pair(f, g, inner, flip ? a1 : a0, flip ? b1 : b0, a1, b1, both, flip, 0., 1e-3, 4096, qpark, r0, qs0, r1, qs1);
+    if (flip) { r1 = r0; qs1 = qs0; }
+    if (todo0) {
+        val0 = r0;
+        if (qs0 != QAG_SUCCESS) {
+            val0 = RIM_NAN;
+            st0 |= ST_INNER_FAIL;
+            if (qs0 == QAG_ESTORE) st0 |= ST_STORE_FULL;
+        }
+    }
+    if (todo1) {
+        val1 = r1;
+        if (qs1 != QAG_SUCCESS) {
+            val1 = RIM_NAN;
+            st1 |= ST_INNER_FAIL;
+            if (qs1 == QAG_ESTORE) st1 |= ST_STORE_FULL;
+        }
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ double hey_eval_request(const HeyPoint &pt, const DistParams &dist, const HeyConsts &hc,
                                                    const GKLane &g, const IStore &inner, QagPark *qpark,
                                                    double u, int qr_flag, int &st)
 {
-    const bool qr = qr_flag != 0;
-    double lo, hi;
-    bool empty = false;
-    if (!qr) {
-        const double sigma_min = rim_sqrt(u * u + pt.sigma0_sq);
-        const double sigma_max = RIM_INVERSE_SQRT_3 * rim_pow(sigma_min, 1.5);
-        empty = sigma_max <= sigma_min;
-        lo = sigma_min; hi = sigma_max;
-    } else {
-        const double pomega_max_phys = rim_sqrt(RIM_THREE_TWO_THIRDS * rim_pow(u, 4. / 3.) - pt.sigma0_sq);
-        const double pomega_max_qr = rim_sqrt(u * u - pt.sigma0_sq);
-        const double pomega_max = rust_min(pomega_max_phys, pomega_max_qr);
-        lo = -pomega_max; hi = pomega_max;
-    }
-    lo = uni(lo); hi = uni(hi);
-    double val = 0.;
-    if (!uni(empty)) {
-        auto f = [&](double v, bool active) -> double {
-            return active ? hey_element<KIND>(pt, dist, hc, qr, u, v) : 0.;
-        };
-        QagState iq;
-        wave_qag(f, g, inner, lo, hi, 0., 1e-3, 4096, iq, qpark);
-        if (g.lane == 0) qpark->ctr.inner_qags += 1;
-        val = uni(iq.result);
-        if (uni(iq.status) != QAG_SUCCESS) {
-            val = RIM_NAN;
-            st |= ST_INNER_FAIL;
-            if (iq.status == QAG_ESTORE) st |= ST_STORE_FULL;
-        }
-    }
-    return val;
+    double v0, v1;
+    int s1 = 0;
+    hey_eval_pair<KIND>(pt, dist, hc, g, inner, qpark, u, qr_flag, u, qr_flag, false, v0, st, v1, s1);
+    return v0;
 }
 
 // Continuation of the phase that posted B (lane k holds the value of request k).
@@ -335,8 +371,19 @@ __device__ __forceinline__ double heyvaerts_coefficient(const HeyPoint &pt, cons
             const int k = __builtin_ffsll((long long) mask) - 1;
             mask &= mask - 1;
             const double u = readlane_d(B.req_n, k);
-            const double val = hey_eval_request<KIND>(pt, dist, hc, g, inner, qpark, u, B.req_lobe, batch_status);
+            int k2 = -1;
+            double u2 = u;
+            if (mask) {
+                k2 = __builtin_ffsll((long long) mask) - 1;
+                mask &= mask - 1;
+                u2 = readlane_d(B.req_n, k2);
+            }
+            double val, val2;
+            int st = 0, st2 = 0;
+            hey_eval_pair<KIND>(pt, dist, hc, g, inner, qpark, u, B.req_lobe, u2, B.req_lobe, k2 >= 0, val, st, val2, st2);
+            batch_status |= st | st2;
             if (lane == k) gval = val;
+            if (lane == k2) gval = val2;
         }
         wv_sync();
         T = *park;

@@ -366,19 +366,10 @@ struct HeyvaertsProblem {
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
     { hey_post(c.pt, g, outer, T, B); }
-    // the two requests are evaluated one after the other, in one inlined loop (no pairing on this path yet)
     static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
-    {
-        v0 = 0.; v1 = 0.;
-#pragma nounroll
-        for (int r = 0; r < (have1 ? 2 : 1); r++) {
-            int st = 0;
-            const double v = hey_eval_request<KIND>(c.pt, c.d, c.hc, g, inner, qp, r ? x1 : x0, r ? tag1 : tag0, st);
-            if (r) { v1 = v; st1 |= st; } else { v0 = v; st0 |= st; }
-        }
-    }
+    { hey_eval_pair<KIND>(c.pt, c.d, c.hc, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
                                                    const SymBatch &B, double gval, int bst)
     { hey_consume(c.pt, g, outer, T, B, gval, bst); }

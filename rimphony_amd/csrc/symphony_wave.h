@@ -258,12 +258,8 @@ __device__ __forceinline__ bool sym_post(const SymPoint &pt, const GKLane &g, co
 }
 
 // One or two requests: gamma_integral(n) for the given lobe (symphony.rs:312-389).  THE integrand site.
-//
-// The first rule application of a gamma-integral uses 31 lanes.  Two requests are therefore started
-// together: lanes 0..30 apply the rule to request 0, lanes 32..62 to request 1 (each half-wave also
-// computes its own request's order data and limits), then request 0's bisections run to the end on
-// the whole wave, then request 1 continues from its parked first-rule result.  Every request sees
-// exactly the arithmetic of a solo evaluation (a half-wave's rule sums never involve the other half).
+// Two requests share their first rule application (wave_qag_pair); each half-wave also computes its own
+// request's order data and limits.
 template <int KIND>
 __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistParams &dist, const GKLane &g,
                                               const IStore &inner, QagPark *qpark,
@@ -289,91 +285,25 @@ __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistPara
     n0 = uni(n0); n1 = uni(n1);
     RIM_PROF_ADD(7, t_setup);
 
-    QagState q;
-    qag_begin(q, 0., 1e-3, 5000);
-    int phase = 0;                   // 0: the joint first rule application, 1: bisections of request `cur`
-    int cur = 0;
-    double fb0 = 0., fb1 = 0., fb2 = 0., fb3 = 0.;
-    val0 = 0.; val1 = 0.;
-    int s0 = 0, s1 = 0;
-
-    for (;;) {
-        double la, lb;
-        bool active, slot1;
-        if (phase == 0) {
-            la = L.g0; lb = L.g1;
-            slot1 = second;
-            active = g.node && (g.half == 0 || have1);
-        } else {
-            RIM_PROF_T(t_pick);
-            qag_pick(q, inner, lane);
-            RIM_PROF_ADD(13, t_pick);
-            la = g.half ? q.a2 : q.a1;
-            lb = g.half ? q.b2 : q.b1;
-            slot1 = cur != 0;
-            active = g.node;
-        }
+    auto f = [&](double x, bool active, bool second) -> double {
         SymOrder so;
-        const int fl = slot1 ? fl1 : fl0;
-        so.n = slot1 ? n1 : n0;
+        const int fl = second ? fl1 : fl0;
+        so.n = second ? n1 : n0;
         so.small = (fl & 1) != 0; so.np1_small = (fl & 2) != 0; so.dj_nan = (fl & 4) != 0;
-        so.o = qpark->ord + (slot1 ? 2 : 0);
-        const double hl = 0.5 * (lb - la);
-        const double x = 0.5 * (la + lb) + hl * g.t;
-        if (lane == 0) {
-            qpark->q = q;
-            qpark->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
-            qpark->ctr.steps += 1;
-            if (qpark->hb) {
-                hb_store(qpark->hb + 3, qpark->ctr.steps);
-                hb_store(qpark->hb + 4, (unsigned long long) q.iteration);
-            }
-        }
-        RIM_PROF_T(t_int);
-        const double fv = active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
-        RIM_PROF_ADD(1, t_int);
-        RIM_PROF_T(t_unpark);
-        wv_sync();
-        q = qpark->q;
-        qag_uniformize(q);
-        RIM_PROF_ADD(14, t_unpark);
-
-        RIM_PROF_T(t_gk);
-        const GKRes r = wave_gk31(fv, hl, g);
-        RIM_PROF_ADD(11, t_gk);
-        bool finished;
-        if (phase == 0) {
-            fb0 = readlane_d(r.result, 32); fb1 = readlane_d(r.abserr, 32);
-            fb2 = readlane_d(r.resabs, 32); fb3 = readlane_d(r.resasc, 32);
-            finished = qag_after_first(q, inner, lane, a0, b0, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
-                                       readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
-            phase = 1;
-        } else {
-            RIM_PROF_T(t_ab);
-            finished = qag_after_bisect(q, inner, lane,
-                                        readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
-                                        readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
-            RIM_PROF_ADD(12, t_ab);
-        }
-        if (!finished) continue;
-
-        // request `cur` is complete
-        for (;;) {
-            double v = uni(q.result);
-            int st = 0;
-            if (uni(q.status) != QAG_SUCCESS) {
-                v = RIM_NAN;
-                st |= ST_INNER_FAIL;
-                if (q.status == QAG_ESTORE) st |= ST_STORE_FULL;
-            }
-            if (lane == 0) qpark->ctr.inner_qags += 1;
-            if (cur == 0) { val0 = v; s0 = st; } else { val1 = v; s1 = st; }
-            if (cur != 0 || !have1) { st0 |= s0; st1 |= s1; return; }
-            // request 1 continues from its parked first-rule result
-            cur = 1;
-            qag_begin(q, 0., 1e-3, 5000);
-            if (!qag_after_first(q, inner, lane, a1, b1, fb0, fb1, fb2, fb3)) break;
-        }
+        so.o = qpark->ord + (second ? 2 : 0);
+        return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
+    };
+    int qs0, qs1;
+    wave_qag_pair(f, g, inner, a0, b0, a1, b1, have1, false, 0., 1e-3, 5000, qpark, val0, qs0, val1, qs1);
+    if (qs0 != QAG_SUCCESS) {
+        val0 = RIM_NAN;
+        st0 |= ST_INNER_FAIL;
+        if (qs0 == QAG_ESTORE) st0 |= ST_STORE_FULL;
+    }
+    if (have1 && qs1 != QAG_SUCCESS) {
+        val1 = RIM_NAN;
+        st1 |= ST_INNER_FAIL;
+        if (qs1 == QAG_ESTORE) st1 |= ST_STORE_FULL;
     }
 }
 

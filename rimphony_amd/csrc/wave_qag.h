@@ -488,5 +488,95 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
     }
 }
 
+// Two adaptive QAGs that share their first rule application.
+//
+// The first GK31 application of an integral uses 31 lanes, so two integrals are started together:
+// lanes 0..30 apply the rule to integral 0 on [a0, b0], lanes 32..62 to integral 1 on [a1, b1]; then
+// integral 0's bisections run to the end on the whole wave, then integral 1 continues from its parked
+// first-rule result.  Each integral sees exactly the arithmetic of wave_qag (a half-wave's rule sums
+// never involve the other half).  f(x, active, second) evaluates the integrand of integral 0 or 1
+// (`second` is per lane during the joint application and uniform afterwards); `flip` swaps the roles
+// (used to run integral 1 alone).  Results: r0/qs0 (and r1/qs1 if have1) = result and GSL status.
+template <class F>
+__device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStore &st,
+                                              double a0, double b0, double a1, double b1, bool have1, bool flip,
+                                              double epsabs, double epsrel, int limit, QagPark *park,
+                                              double &r0, int &qs0, double &r1, int &qs1)
+{
+    const int lane = g.lane;
+    QagState q;
+    qag_begin(q, epsabs, epsrel, limit);
+    int phase = 0;                   // 0: the joint first rule application, 1: bisections of integral `cur`
+    int cur = 0;
+    double fb0 = 0., fb1 = 0., fb2 = 0., fb3 = 0.;
+    r0 = 0.; r1 = 0.; qs0 = QAG_SUCCESS; qs1 = QAG_SUCCESS;
+
+    for (;;) {
+        double la, lb;
+        bool active, second;
+        if (phase == 0) {
+            second = g.half != 0 && have1;
+            la = second ? a1 : a0;
+            lb = second ? b1 : b0;
+            active = g.node && (g.half == 0 || have1);
+        } else {
+            RIM_PROF_T(t_pick);
+            qag_pick(q, st, lane);
+            RIM_PROF_ADD(13, t_pick);
+            la = g.half ? q.a2 : q.a1;
+            lb = g.half ? q.b2 : q.b1;
+            second = cur != 0;
+            active = g.node;
+        }
+        const double hl = 0.5 * (lb - la);
+        const double x = 0.5 * (la + lb) + hl * g.t;
+        if (lane == 0) {
+            park->q = q;
+            park->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
+            park->ctr.steps += 1;
+            if (park->hb) {
+                hb_store(park->hb + 3, park->ctr.steps);
+                hb_store(park->hb + 4, (unsigned long long) q.iteration);
+            }
+        }
+        RIM_PROF_T(t_int);
+        const double fv = f(x, active, second != flip);
+        RIM_PROF_ADD(1, t_int);
+        RIM_PROF_T(t_unpark);
+        wv_sync();
+        q = park->q;
+        qag_uniformize(q);
+        RIM_PROF_ADD(14, t_unpark);
+
+        RIM_PROF_T(t_gk);
+        const GKRes r = wave_gk31(fv, hl, g);
+        RIM_PROF_ADD(11, t_gk);
+        bool finished;
+        if (phase == 0) {
+            fb0 = readlane_d(r.result, 32); fb1 = readlane_d(r.abserr, 32);
+            fb2 = readlane_d(r.resabs, 32); fb3 = readlane_d(r.resasc, 32);
+            finished = qag_after_first(q, st, lane, a0, b0, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
+                                       readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
+            phase = 1;
+        } else {
+            RIM_PROF_T(t_ab);
+            finished = qag_after_bisect(q, st, lane,
+                                        readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
+                                        readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+            RIM_PROF_ADD(12, t_ab);
+        }
+        if (!finished) continue;
+
+        for (;;) {                   // integral `cur` is complete
+            if (lane == 0) park->ctr.inner_qags += 1;
+            if (cur == 0) { r0 = uni(q.result); qs0 = uni(q.status); } else { r1 = uni(q.result); qs1 = uni(q.status); }
+            if (cur != 0 || !have1) return;
+            cur = 1;                 // integral 1 continues from its parked first-rule result
+            qag_begin(q, epsabs, epsrel, limit);
+            if (!qag_after_first(q, st, lane, a1, b1, fb0, fb1, fb2, fb3)) break;
+        }
+    }
+}
+
 }  // namespace rim
 #endif
