@@ -232,6 +232,19 @@ __device__ __forceinline__ void qag_uniformize(QagState &q)
     q.status = uni(q.status); q.result = uni(q.result); q.abserr = uni(q.abserr);
 }
 
+// The same for the fields that are live between two passes of a running QAG; the tolerances and the
+// limit are re-imposed from the caller's (constant) arguments, status/result/abserr are outputs.
+__device__ __forceinline__ void qag_uniformize_live(QagState &q, double epsabs, double epsrel, int limit)
+{
+    q.epsabs = epsabs; q.epsrel = epsrel; q.limit = limit;
+    q.area = uni(q.area); q.errsum = uni(q.errsum); q.tolerance = uni(q.tolerance);
+    q.iteration = uni(q.iteration); q.rt1 = uni(q.rt1); q.rt2 = uni(q.rt2);
+    q.error_type = uni(q.error_type); q.size = uni(q.size); q.imax = uni(q.imax);
+    q.a1 = uni(q.a1); q.b1 = uni(q.b1); q.a2 = uni(q.a2); q.b2 = uni(q.b2);
+    q.r_i = uni(q.r_i); q.e_i = uni(q.e_i);
+    q.status = QAG_SUCCESS; q.result = 0.; q.abserr = 0.;
+}
+
 __device__ __forceinline__ void qag_begin(QagState &q, double epsabs, double epsrel, int limit)
 {
     q.epsabs = epsabs;
@@ -545,7 +558,7 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
         RIM_PROF_T(t_unpark);
         wv_sync();
         q = park->q;
-        qag_uniformize(q);
+        qag_uniformize_live(q, epsabs, epsrel, limit);
         RIM_PROF_ADD(14, t_unpark);
 
         RIM_PROF_T(t_gk);
