@@ -127,8 +127,11 @@ int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_w
  * [1..3] Symphony samples / passes / inner QAGs, [4] Faraday task head, [5..7] Faraday work,
  * [8] batches published on the assist board, [9] requests evaluated by helper waves,
  * [10] requests of published batches evaluated by their owner, [11] owner wait (100 MHz ticks),
- * [12] helper polls, [13] helper visits that found every request already claimed. */
-int rimphony_debug_counters(rimphony_ctx *ctx, uint64_t out[16]);
+ * [12] helper polls, [13] helper visits that found every request already claimed, [14] ticks spent
+ * evaluating requests, [15] longest owner wait.  Words 8..15 are only counted by a library built with
+ * -DRIM_COOP_DIAG (tools/ab_assist.py); they are 0 otherwise.  `out` must hold 32 words (a -DRIM_PROF build
+ * returns its 32 region timers instead, tools/region_profile.py). */
+int rimphony_debug_counters(rimphony_ctx *ctx, uint64_t out[32]);
 
 /* The batched compute(): N x (full_calculation + compute_all_dimensionless).
  *   d_s, d_theta   [n]                device

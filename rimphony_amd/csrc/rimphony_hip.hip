@@ -406,8 +406,14 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     bool counted_idle = false;             // this wave is currently counted in flags[IDLE]
     int backoff = 1;
     // diagnostics of the cooperative tail (queue words 8..13)
-    unsigned long long n_shared_batches = 0, n_helper_reqs = 0, n_owner_shared_reqs = 0, wait_ticks = 0, n_polls = 0,
-                       n_empty_claims = 0, eval_ticks = 0, max_wait = 0;
+    unsigned n_polls = 0;
+#if defined(RIM_COOP_DIAG)
+    unsigned long long n_shared_batches = 0, n_helper_reqs = 0, n_owner_shared_reqs = 0, wait_ticks = 0,
+                       n_empty_claims = 0, eval_ticks = 0, max_wait = 0, n_polls_total = 0;
+#define COOP_DIAG(x) x
+#else
+#define COOP_DIAG(x)
+#endif
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     typename P::Ctx cx;                    // context of the requests being evaluated (own task or a helped one)
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             if (shared) {
                 seq += 1;
                 src_seq = seq;
-                n_shared_batches += 1;
+                COOP_DIAG(n_shared_batches += 1;)
                 if (B.req_active) {
                     const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                     bput(&my->req_n[rank], rim_bits(B.req_n));
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             int leave = 0;
             unsigned long long c = 0;
             if (lane == 0) {
-                if ((n_polls & 15ull) == 0) {
+                if ((n_polls & 15u) == 0) {
                     act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // More idle waves than the remaining owners can feed (a batch has <= 62 requests) only
                     // add polling traffic, which slows the waves that compute: the surplus leaves.
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
             if (__builtin_amdgcn_readfirstlane(leave)) break;
             n_polls += 1;
+            COOP_DIAG(n_polls_total += 1;)
             if (h == 0) {
                 if (act == 0) break;       // every task is finished
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             }
             if (k < 0) break;
             got += 1;
-            if (shared) { if (helper) n_helper_reqs += 1; else n_owner_shared_reqs += 1; }
+            COOP_DIAG(if (shared) { if (helper) n_helper_reqs += 1; else n_owner_shared_reqs += 1; })
             double n;
             int lb;
             if (helper) {
@@ -635,11 +642,11 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             }
             int st = 0, st2 = 0;
             double val, val2;
-            const unsigned long long e0 = wall_clock64();
+            COOP_DIAG(const unsigned long long e0 = wall_clock64();)
             RIM_PROF_T(t_req);
             P::eval2(cx, g, inner, &s_qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
             RIM_PROF_ADD(9, t_req);
-            eval_ticks += wall_clock64() - e0;
+            COOP_DIAG(eval_ticks += wall_clock64() - e0;)
             if (shared) {
                 if (lane == 0) {
                     bput(&src->res[k], rim_bits(val));
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 // every request of that batch was already taken: back off before looking again
                 // (last_hint is not set here: the claim word is re-read on the next poll, and that
                 // poll files the hint away once the batch shows no open request)
-                n_empty_claims += 1;
+                COOP_DIAG(n_empty_claims += 1;)
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
                 if (backoff < 16) backoff *= 2;
             } else {
@@ -680,9 +687,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 dn = (unsigned) __builtin_amdgcn_readfirstlane((int) dn);
                 if (dn >= want) {
                     complete = true;
-                    const unsigned long long w = wall_clock64() - t0;
-                    wait_ticks += w;
-                    if (w > max_wait) max_wait = w;
+                    COOP_DIAG(const unsigned long long w = wall_clock64() - t0; wait_ticks += w; if (w > max_wait) max_wait = w;)
                     break;
                 }
                 if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
@@ -716,14 +721,16 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         atomicAdd(queue + 1, s_qpark.ctr.samples);
         atomicAdd(queue + 2, s_qpark.ctr.steps);
         atomicAdd(queue + 3, s_qpark.ctr.inner_qags);
+#if defined(RIM_COOP_DIAG)
         atomicAdd(a.queue + 8, n_shared_batches);
         atomicAdd(a.queue + 9, n_helper_reqs);
         atomicAdd(a.queue + 10, n_owner_shared_reqs);
         atomicAdd(a.queue + 11, wait_ticks);
-        atomicAdd(a.queue + 12, n_polls);
+        atomicAdd(a.queue + 12, n_polls_total);
         atomicAdd(a.queue + 13, n_empty_claims);
         atomicAdd(a.queue + 14, eval_ticks);
         atomicMax(a.queue + 15, max_wait);
+#endif
     }
 }
 
@@ -1230,7 +1237,7 @@ extern "C" int rimphony_debug_heartbeat(rimphony_ctx *c, uint64_t task, uint64_t
     return RIMPHONY_OK;
 }
 
-extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[16])
+extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[32])
 {
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1245,6 +1252,7 @@ extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[16])
         return RIMPHONY_OK;
     }
 #endif
+    for (int k = 16; k < 32; k++) out[k] = 0;
     HIP_TRY(hipMemcpy(out, c->d_queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RIMPHONY_OK;
 }
