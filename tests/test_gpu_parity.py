@@ -259,3 +259,26 @@ def test_results_independent_of_batch_composition(gpu_ctx):
     sub = slice(1, 64, 2)
     part = gpu_ctx.compute_batch(kind, s[sub], th[sub], [p[sub] for p in params], mask)
     assert same_bits(full[sub][:, :2], part[:, :2]).all()
+
+
+def test_cooperative_tail_changes_no_bit(gpu_ctx):
+    """The assist board only changes WHO evaluates a gamma-integral / inner integral: a context created with
+    RIMPHONY_NO_ASSIST=1 (one wave per task to the end) must return the same bits, status words included, for
+    all eight coefficients -- on a batch small enough that most of it runs in the cooperative regime."""
+    import os
+    from rimphony_amd import api
+    kind, mask, s, th, params = workload.make_batch("cfg4_pitchypl_8", 96, start=5000)
+    coop, st_coop = gpu_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    old = os.environ.get("RIMPHONY_NO_ASSIST")
+    os.environ["RIMPHONY_NO_ASSIST"] = "1"
+    try:
+        solo_ctx = api.Context(0)
+    finally:
+        if old is None:
+            del os.environ["RIMPHONY_NO_ASSIST"]
+        else:
+            os.environ["RIMPHONY_NO_ASSIST"] = old
+    solo, st_solo = solo_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    solo_ctx.close()
+    assert same_bits(coop, solo).all()
+    assert (st_coop == st_solo).all()
