@@ -133,7 +133,7 @@ static double dfdsigma(const hey_state *st)
         const double t = st->sigma0 * st->sin_observer_angle;
         const double u = q * q - t * t;
         const double dcxi_dsigma = (q * u * st->cos_observer_angle + u * r + r * (t * t))
-            / (m_pow(u, 1.5) * q);
+            / (m_pow15(u) * q);
         mu_term = dcxi_dsigma * dfdcxi;
     }
     return g_term + mu_term;
@@ -143,7 +143,7 @@ static double h_qr_element(const hey_state *st)
 {
     const double po_sq = st->pomega * st->pomega;
     const double smxox = (st->sigma - st->x) / st->x;
-    const double g = SQRT_8_OVER_3 * m_pow(st->sigma - st->x, 1.5) / m_sqrt(st->x);
+    const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
     double y;
 
     if (g < G_APPROXIMATION_CUTOFF) {
@@ -181,9 +181,9 @@ static double h_nr_element(const hey_state *st)
     const double a1 = 1. / 8. - 5. / 24. * s_sq / ssqmxsq;
     const double a2 = 3. / 128. - 77. / 576. * s_sq / ssqmxsq + 385. / 3456. * (ratio * ratio);
     const double xa1p = -5. / 12. * s_sq * x_sq / (ssqmxsq * ssqmxsq);
-    const double t1 = (6. * a2 - a1 * a1 + xa1p) / m_sqrt(ssqmxsq) + a1 * x_sq / m_pow(ssqmxsq, 1.5)
-        - (x_sq * x_sq) / m_pow(ssqmxsq, 2.5) / 8.;
-    const double t2 = (6. * a2 - a1 * a1) / m_pow(ssqmxsq, 1.5);
+    const double t1 = (6. * a2 - a1 * a1 + xa1p) / m_sqrt(ssqmxsq) + a1 * x_sq / m_pow15(ssqmxsq)
+        - (x_sq * x_sq) / m_pow25(ssqmxsq) / 8.;
+    const double t2 = (6. * a2 - a1 * a1) / m_pow15(ssqmxsq);
     const double u1 = 2. * t1 - st->sigma0_sq * t2;
     const double dfds = dfdsigma(st);
     return RIM_PI * INVERSE_C * u1 * dfds;
@@ -191,7 +191,7 @@ static double h_nr_element(const hey_state *st)
 
 static double f_qr_element(const hey_state *st)
 {
-    const double g = SQRT_8_OVER_3 * m_pow(st->sigma - st->x, 1.5) / m_sqrt(st->x);
+    const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
     double y;
     if (g < G_APPROXIMATION_CUTOFF) {
         y = INVERSE_SQRT_3
@@ -216,7 +216,7 @@ static double f_nr_element(const hey_state *st)
     const double a2 = 3. / 128. - 77. / 576. * s_sq / ssqmxsq + 385. / 3456. * (ratio * ratio);
     const double xa1p = -5. / 12. * s_sq * x_sq / (ssqmxsq * ssqmxsq);
     const double z =
-        0.5 * x_sq / m_pow(ssqmxsq, 1.5)
+        0.5 * x_sq / m_pow15(ssqmxsq)
         + (6. * a2 + xa1p - a1 * a1) / ssqmxsq
         + 1.5 * a1 * x_sq / (ssqmxsq * ssqmxsq);
     const double dfds = dfdsigma(st);

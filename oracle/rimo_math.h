@@ -14,6 +14,7 @@
 #define m_log10(x) log10(x)
 #define m_pow(x, y) pow(x, y)
 #define m_pow15(x) pow(x, 1.5)
+#define m_pow25(x) pow(x, 2.5)
 #define m_lgamma(x) lgamma(x)
 static inline void m_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
 #define m_fma(a, b, c) ((a) * (b) + (c)) /* the reference never fuses */
@@ -23,6 +24,7 @@ static inline void m_sincos(double x, double *s, double *c) { *s = sin(x); *c = 
 #define m_log10(x) rim_log10(x)
 #define m_pow(x, y) rim_pow(x, y)
 #define m_pow15(x) rim_pow15(x)
+#define m_pow25(x) rim_pow25(x)
 #define m_lgamma(x) rim_lgamma_pos(x)
 static inline void m_sincos(double x, double *s, double *c) { rim_sincos(x, s, c); }
 #define m_fma(a, b, c) rim_fma(a, b, c)

@@ -257,6 +257,8 @@ RIM_FN double rim_pow(double x, double y)
 
 /* x^1.5 for x >= 0 as x * sqrt(x) (two roundings; used by the GK error rescaling, qk.c) */
 RIM_FN double rim_pow15(double x) { return x * rim_sqrt(x); }
+/* x^2.5 as x^2 * sqrt(x) (three roundings) */
+RIM_FN double rim_pow25(double x) { return (x * x) * rim_sqrt(x); }
 
 /* ---- lgamma (positive arguments only) --------------------------------- */
 

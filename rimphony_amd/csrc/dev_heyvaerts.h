@@ -115,7 +115,7 @@ RIM_DEV double dfdsigma(const HeyPoint &pt, const DistParams &d, const HeyCoord 
         const double r = c.pomega - c.sigma * pt.cos_th;
         const double t = pt.sigma0 * pt.sin_th;
         const double u = q * q - t * t;
-        const double dcxi_dsigma = (q * u * pt.cos_th + u * r + r * (t * t)) / (rim_pow(u, 1.5) * q);
+        const double dcxi_dsigma = (q * u * pt.cos_th + u * r + r * (t * t)) / (rim_pow15(u) * q);
         mu_term = dcxi_dsigma * dfdcxi;
     }
     return g_term + mu_term;
@@ -126,7 +126,7 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
 {
     const double po_sq = c.pomega * c.pomega;
     const double smxox = (c.sigma - c.x) / c.x;
-    const double g = RIM_SQRT_8_OVER_3 * rim_pow(c.sigma - c.x, 1.5) / rim_sqrt(c.x);
+    const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
     double y1, y2;
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
         const double plus = bessel_i_g(2. / 3., hc.g_p23, g);
@@ -166,9 +166,9 @@ RIM_DEV double h_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
 {
     double a1, a2, xa1p, ssqmxsq, x_sq;
     nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
-    const double t1 = (6. * a2 - a1 * a1 + xa1p) / rim_sqrt(ssqmxsq) + a1 * x_sq / rim_pow(ssqmxsq, 1.5)
-        - (x_sq * x_sq) / rim_pow(ssqmxsq, 2.5) / 8.;
-    const double t2 = (6. * a2 - a1 * a1) / rim_pow(ssqmxsq, 1.5);
+    const double t1 = (6. * a2 - a1 * a1 + xa1p) / rim_sqrt(ssqmxsq) + a1 * x_sq / rim_pow15(ssqmxsq)
+        - (x_sq * x_sq) / rim_pow25(ssqmxsq) / 8.;
+    const double t2 = (6. * a2 - a1 * a1) / rim_pow15(ssqmxsq);
     const double u1 = 2. * t1 - pt.sigma0_sq * t2;
     const double dfds = dfdsigma<KIND>(pt, d, c);
     return RIM_PI * RIM_INVERSE_C * u1 * dfds;
@@ -177,7 +177,7 @@ RIM_DEV double h_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
 template <int KIND>
 RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, const HeyCoord &c)
 {
-    const double g = RIM_SQRT_8_OVER_3 * rim_pow(c.sigma - c.x, 1.5) / rim_sqrt(c.x);
+    const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
     double y;
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
         y = RIM_INVERSE_SQRT_3
@@ -198,7 +198,7 @@ RIM_DEV double f_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     double a1, a2, xa1p, ssqmxsq, x_sq;
     nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
     const double z =
-        0.5 * x_sq / rim_pow(ssqmxsq, 1.5)
+        0.5 * x_sq / rim_pow15(ssqmxsq)
         + (6. * a2 + xa1p - a1 * a1) / ssqmxsq
         + 1.5 * a1 * x_sq / (ssqmxsq * ssqmxsq);
     const double dfds = dfdsigma<KIND>(pt, d, c);
