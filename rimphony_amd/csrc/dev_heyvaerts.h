@@ -48,11 +48,39 @@ RIM_DEV double ascending_series(double nu, double q, double sign)
     return sum;
 }
 
-// I_nu(x) with Gamma(nu + 1) supplied
-RIM_DEV double bessel_i_g(double nu, double gam, double x)
+// The four fixed orders of the quasi-resonant elements (nu = 2/3, -2/3, 1/3, -1/3) divide every series
+// term by k (k + nu), a number that depends on nothing else: a table of those divisors and of their
+// correctly rounded reciprocals turns each of the ~40 divisions per series into the exact 3-operation
+// form (rim_div_by).  Layout: [4 orders][RIM_SERIES_TERMS + 1][2] doubles = {k (k + nu), 1 / that}.
+#define RIM_SERIES_TERMS 500
+#define RIM_SERIES_ROW (2 * (RIM_SERIES_TERMS + 1))
+
+RIM_DEV double hey_series_order(int j) { return j == 0 ? 2. / 3. : j == 1 ? -2. / 3. : j == 2 ? 1. / 3. : -1. / 3.; }
+
+RIM_DEV void hey_series_table_entry(int j, int k, double *entry)
+{
+    const double nu = hey_series_order(j);
+    const double b = k * (k + nu);
+    entry[0] = b;
+    entry[1] = 1. / b;
+}
+
+RIM_DEV double ascending_series_tab(const double *row, double q, double sign)
+{
+    double term = 1., sum = 1.;
+    for (int k = 1; k <= RIM_SERIES_TERMS; k++) {
+        term = term * rim_div_by(sign * q, row[2 * k], row[2 * k + 1]);
+        sum = sum + term;
+        if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
+    }
+    return sum;
+}
+
+// I_nu(x) for the j-th tabulated order, with Gamma(nu + 1) supplied
+RIM_DEV double bessel_i_g(int j, double gam, const double *tab, double x)
 {
     const double h = 0.5 * x;
-    return rim_pow(h, nu) / gam * ascending_series(nu, h * h, 1.);
+    return rim_pow(h, hey_series_order(j)) / gam * ascending_series_tab(tab + j * RIM_SERIES_ROW, h * h, 1.);
 }
 
 RIM_DEV double bessel_jnu(double nu, double x)
@@ -69,12 +97,28 @@ RIM_DEV double bessel_ynu(double nu, double x)
     return (cs * bessel_jnu(nu, x) - bessel_jnu(-nu, x)) / sn;
 }
 
-// Per-task constants: Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3.
-struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; };
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host builds (CPU tests, wavefront emulator): the table in static storage, filled on first use
+inline const double *hey_series_table_host()
+{
+    static double tab[4 * RIM_SERIES_ROW];
+    static bool ready = false;
+    if (!ready) {
+        for (int j = 0; j < 4; j++)
+            for (int k = 1; k <= RIM_SERIES_TERMS; k++) hey_series_table_entry(j, k, tab + j * RIM_SERIES_ROW + 2 * k);
+        ready = true;
+    }
+    return tab;
+}
+#endif
 
-RIM_DEV HeyConsts hey_consts()
+// Per-task constants: Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3, and the series divisor table.
+struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; const double *tab; };
+
+RIM_DEV HeyConsts hey_consts(const double *series_tab)
 {
     HeyConsts c;
+    c.tab = series_tab;
     c.g_p23 = gamma_real(2. / 3. + 1.);
     c.g_m23 = gamma_real(-2. / 3. + 1.);
     c.g_p13 = gamma_real(1. / 3. + 1.);
@@ -129,11 +173,11 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
     double y1, y2;
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
-        const double plus = bessel_i_g(2. / 3., hc.g_p23, g);
-        const double minus = bessel_i_g(-2. / 3., hc.g_m23, g);
+        const double plus = bessel_i_g(0, hc.g_p23, hc.tab, g);
+        const double minus = bessel_i_g(1, hc.g_m23, hc.tab, g);
         y1 = RIM_FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
-        const double plus1 = bessel_i_g(1. / 3., hc.g_p13, g);
-        const double minus1 = bessel_i_g(-1. / 3., hc.g_m13, g);
+        const double plus1 = bessel_i_g(2, hc.g_p13, hc.tab, g);
+        const double minus1 = bessel_i_g(3, hc.g_m13, hc.tab, g);
         y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
     } else {
         const double js = bessel_jnu(c.sigma, c.x);
@@ -182,8 +226,8 @@ RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
         y = RIM_INVERSE_SQRT_3
             * g
-            * (bessel_i_g(-2. / 3., hc.g_m23, g) - bessel_i_g(2. / 3., hc.g_p23, g))
-            * (bessel_i_g(-1. / 3., hc.g_m13, g) + bessel_i_g(1. / 3., hc.g_p13, g));
+            * (bessel_i_g(1, hc.g_m23, hc.tab, g) - bessel_i_g(0, hc.g_p23, hc.tab, g))
+            * (bessel_i_g(3, hc.g_m13, hc.tab, g) + bessel_i_g(2, hc.g_p13, hc.tab, g));
     } else {
         const double jvp = bessel_jnu(c.sigma - 1., c.x) - c.sigma * bessel_jnu(c.sigma, c.x) / c.x;
         y = -c.x * jvp * bessel_ynu(c.sigma, c.x);

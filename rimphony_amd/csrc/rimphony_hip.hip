@@ -164,6 +164,7 @@ struct SymArgs {
     double *spill;                  // [gridDim.x][SPILL_DOUBLES_PER_WAVE] wave-private global store overflow
     struct AssistSlot *board;       // [gridDim.x] cooperative-tail board (null: cooperation off)
     unsigned *board_flags;          // [0] task queue exhausted, [1] waves that still own / may fetch a task
+    const double *series_tab;       // Heyvaerts: divisors of the fixed-order Bessel series and their reciprocals
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
 };
@@ -313,7 +314,7 @@ struct SymphonyProblem {
     struct Ctx { SymPoint pt; DistParams d; };
     typedef TaskState Task;
     enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0 };
-    static __device__ __forceinline__ void init(Ctx &) {}
+    static __device__ __forceinline__ void init(const SymArgs &, Ctx &) {}
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     { load_context<KIND>(a, i, slot, c.pt, c.d, norm); }
     static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { sym_begin(c.pt, T); }
@@ -337,9 +338,9 @@ struct HeyvaertsProblem {
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
     typedef HeyTask Task;
     enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62 };
-    static __device__ __forceinline__ void init(Ctx &c)
+    static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c)
     {
-        c.hc = hey_consts();
+        c.hc = hey_consts(a.series_tab);
         c.hc.g_p23 = uni(c.hc.g_p23); c.hc.g_m23 = uni(c.hc.g_m23); c.hc.g_p13 = uni(c.hc.g_p13); c.hc.g_m13 = uni(c.hc.g_m13);
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     typename P::Ctx cx;                    // context of the requests being evaluated (own task or a helped one)
-    P::init(cx);
+    P::init(a, cx);
     unsigned long long *const queue = a.queue + P::QUEUE;
     // The own task's state lives in LDS (s_park) between the three places that touch it, so that it
     // never occupies registers while the integrand runs.
@@ -734,6 +735,15 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     }
 }
 
+__global__ void series_table_kernel(double *tab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * (RIM_SERIES_TERMS + 1)) return;
+    const int j = i / (RIM_SERIES_TERMS + 1), k = i % (RIM_SERIES_TERMS + 1);
+    if (k == 0) { tab[j * RIM_SERIES_ROW] = 0.; tab[j * RIM_SERIES_ROW + 1] = 0.; return; }
+    hey_series_table_entry(j, k, tab + j * RIM_SERIES_ROW + 2 * k);
+}
+
 __global__ void board_init_kernel(unsigned *flags, unsigned active)
 {
     const unsigned i = threadIdx.x;
@@ -921,6 +931,7 @@ struct rimphony_ctx {
     hipEvent_t ev_start, ev_stop;   // Symphony launch
     int ev_valid;
     hipEvent_t ev_fstart, ev_fstop; // Faraday launch
+    double *d_series;               // Heyvaerts series divisor table (dev_heyvaerts.h)
     int evf_valid;
     // diagnostics: heartbeat words in host-mapped memory
     unsigned long long *hb_host;
@@ -982,6 +993,18 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
         delete c;
         return RIMPHONY_EHIP;
     }
+    if (hipMalloc(&c->d_series, 4 * RIM_SERIES_ROW * sizeof(double)) != hipSuccess) {
+        (void) hipFree(c->d_queue);
+        delete c;
+        return RIMPHONY_ENOMEM;
+    }
+    hipLaunchKernelGGL(series_table_kernel, dim3((4 * (RIM_SERIES_TERMS + 1) + 255) / 256), dim3(256), 0, (hipStream_t) 0, c->d_series);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        (void) hipFree(c->d_series);
+        (void) hipFree(c->d_queue);
+        delete c;
+        return RIMPHONY_EHIP;
+    }
     *out = c;
     return RIMPHONY_OK;
 }
@@ -991,6 +1014,7 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
     if (!c) return;
     (void) hipSetDevice(c->device);
     if (c->d_queue) (void) hipFree(c->d_queue);
+    if (c->d_series) (void) hipFree(c->d_series);
     if (c->d_norm) (void) hipFree(c->d_norm);
     if (c->d_perm) (void) hipFree(c->d_perm);
     if (c->d_spill) (void) hipFree(c->d_spill);
@@ -1179,6 +1203,7 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
         HIP_TRY(hipGetLastError());
         a.perm = c->d_perm;
     }
+    a.series_tab = c->d_series;
     a.heartbeat = c->hb_dev;
     a.hb_task = c->hb_task;
     a.nslots = 0;
