@@ -97,6 +97,44 @@ RIM_DEV double bessel_ynu(double nu, double x)
     return (cs * bessel_jnu(nu, x) - bessel_jnu(-nu, x)) / sn;
 }
 
+// J_sigma, Y_sigma, J_{sigma-1} and (if want_ym1) Y_{sigma-1} at x, as x.besselj(nu) / x.bessely(nu) return them
+// (heyvaerts.rs:335-336, 359-363, 437-441).  Y_nu = (cos(pi nu) J_nu - J_{-nu}) / sin(pi nu) needs J_nu again, so a
+// literal transcription sums the same series twice; here every distinct series is summed once, in one loop
+// body: orders sigma, sigma - 1, their negatives, and -- only for the integer orders that bessel_ynu
+// perturbs -- the perturbed orders.  Each value is the one bessel_jnu / bessel_ynu return.
+RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, double *ys, double *jm1, double *ym1)
+{
+    double nu_y[2], sn[2], cs[2];
+    for (int w = 0; w < 2; w++) {
+        double nu = sigma - (double) w;
+        if (nu == rim_floor(nu)) nu = nu + 1.4901161193847656e-08 * (rim_fabs(nu) > 1. ? rim_fabs(nu) : 1.);
+        nu_y[w] = nu;
+        rim_sincos(RIM_PI * nu, &sn[w], &cs[w]);
+    }
+    // jobs: 0 J(sigma), 1 J(sigma-1), 2 J(-nu_y0), 3 J(-nu_y1), 4 J(nu_y0) if perturbed, 5 J(nu_y1) if perturbed
+    double r[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int k = 0; k < 6; k++) {
+        const int w = k & 1;
+        double nu;
+        bool need;
+        if (k < 2) { nu = sigma - (double) w; need = true; }
+        else if (k < 4) { nu = -nu_y[w]; need = w == 0 || want_ym1; }
+        else { nu = nu_y[w]; need = (w == 0 || want_ym1) && nu_y[w] != sigma - (double) w; }
+        double v = 0.;
+        if (need) v = bessel_jnu(nu, x);
+        r[k] = v;
+    }
+    *js = r[0];
+    *jm1 = r[1];
+    const double j0 = (nu_y[0] != sigma) ? r[4] : r[0];
+    *ys = (cs[0] * j0 - r[2]) / sn[0];
+    const double j1 = (nu_y[1] != sigma - 1.) ? r[5] : r[1];
+    *ym1 = want_ym1 ? (cs[1] * j1 - r[3]) / sn[1] : 0.;
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // host builds (CPU tests, wavefront emulator): the table in static storage, filled on first use
 inline const double *hey_series_table_host()
@@ -172,6 +210,11 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     const double smxox = (c.sigma - c.x) / c.x;
     const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
     double y1, y2;
+    RIM_PROF_COUNT(22, 1);
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    { const unsigned long long big = __ballot(!(g < RIM_G_APPROXIMATION_CUTOFF)); RIM_PROF_COUNT(23, big != 0 ? 1 : 0);
+      RIM_PROF_COUNT(24, __builtin_popcountll(big)); }
+#endif
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
         const double plus = bessel_i_g(0, hc.g_p23, hc.tab, g);
         const double minus = bessel_i_g(1, hc.g_m23, hc.tab, g);
@@ -180,10 +223,10 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
         const double minus1 = bessel_i_g(3, hc.g_m13, hc.tab, g);
         y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
     } else {
-        const double js = bessel_jnu(c.sigma, c.x);
-        const double ys = bessel_ynu(c.sigma, c.x);
-        const double jvp = bessel_jnu(c.sigma - 1., c.x) - c.sigma * js / c.x;
-        const double yvp = bessel_ynu(c.sigma - 1., c.x) - c.sigma * ys / c.x;
+        double js, ys, jm1, ym1;
+        bessel_jy_set(c.sigma, c.x, true, &js, &ys, &jm1, &ym1);
+        const double jvp = jm1 - c.sigma * js / c.x;
+        const double yvp = ym1 - c.sigma * ys / c.x;
         y1 = jvp * yvp;
         y2 = -js * ys;
     }
@@ -229,8 +272,10 @@ RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
             * (bessel_i_g(1, hc.g_m23, hc.tab, g) - bessel_i_g(0, hc.g_p23, hc.tab, g))
             * (bessel_i_g(3, hc.g_m13, hc.tab, g) + bessel_i_g(2, hc.g_p13, hc.tab, g));
     } else {
-        const double jvp = bessel_jnu(c.sigma - 1., c.x) - c.sigma * bessel_jnu(c.sigma, c.x) / c.x;
-        y = -c.x * jvp * bessel_ynu(c.sigma, c.x);
+        double js, ys, jm1, ym1;
+        bessel_jy_set(c.sigma, c.x, false, &js, &ys, &jm1, &ym1);
+        const double jvp = jm1 - c.sigma * js / c.x;
+        y = -c.x * jvp * ys;
     }
     const double dfds = dfdsigma<KIND>(pt, d, c);
     return -(2. * RIM_PI) * RIM_INVERSE_C * c.pomega * (RIM_PI * y - 1.) * dfds;
@@ -255,11 +300,17 @@ template <int KIND>
 RIM_DEV double hey_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, bool qr, double fixed, double v)
 {
     if (qr) {
+        RIM_PROF_T(t_qr);
         const HeyCoord c = fill_coord_vars(pt, fixed, v);
-        return pt.stokes == STOKES_Q ? h_qr_element<KIND>(pt, d, hc, c) : f_qr_element<KIND>(pt, d, hc, c);
+        const double r = pt.stokes == STOKES_Q ? h_qr_element<KIND>(pt, d, hc, c) : f_qr_element<KIND>(pt, d, hc, c);
+        RIM_PROF_ADD(19, t_qr);
+        return r;
     }
+    RIM_PROF_T(t_nr);
     const HeyCoord c = fill_coord_vars(pt, v, fixed);
-    return pt.stokes == STOKES_Q ? h_nr_element<KIND>(pt, d, c) : f_nr_element<KIND>(pt, d, c);
+    const double r = pt.stokes == STOKES_Q ? h_nr_element<KIND>(pt, d, c) : f_nr_element<KIND>(pt, d, c);
+    RIM_PROF_ADD(18, t_nr);
+    return r;
 }
 
 }  // namespace rim
