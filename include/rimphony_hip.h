@@ -128,7 +128,7 @@ int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_w
  * [8] batches published on the assist board, [9] requests evaluated by helper waves,
  * [10] requests of published batches evaluated by their owner, [11] owner wait (100 MHz ticks),
  * [12] helper polls, [13] helper visits that found every request already claimed, [14] ticks spent
- * evaluating requests, [15] longest owner wait.  Words 8..15 are only counted by a library built with
+ * evaluating requests, [15] the task with the most batches as (batches << 24) | point index.  Words 8..15 are only counted by a library built with
  * -DRIM_COOP_DIAG (tools/ab_assist.py); they are 0 otherwise.  `out` must hold 32 words (a -DRIM_PROF build
  * returns its 32 region timers instead, tools/region_profile.py). */
 int rimphony_debug_counters(rimphony_ctx *ctx, uint64_t out[32]);

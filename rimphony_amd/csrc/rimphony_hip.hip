@@ -486,6 +486,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (finished) {
                     int st = 0;
                     const double val = P::result(cx, T, st);
+                    COOP_DIAG(if (lane == 0) atomicMax(a.queue + 15, ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));)
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
                         if (a.status) a.status[own_i * 8 + own_slot] = st;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         atomicAdd(a.queue + 12, n_polls_total);
         atomicAdd(a.queue + 13, n_empty_claims);
         atomicAdd(a.queue + 14, eval_ticks);
-        atomicMax(a.queue + 15, max_wait);
+        (void) max_wait;          // [15] is the heaviest task: (batches << 24) | point index
 #endif
     }
 }

@@ -15,7 +15,7 @@ out, st = ctx.compute_batch_device(kind, ds, dth, dp, 0xC0, want_status=True)
 torch.cuda.synchronize()
 print("wall %.2f s" % (time.perf_counter() - t), ctx.last_work())
 c = ctx.debug_counters()
-for w in (14, 15):
-    passes, idx = c[w] >> 24, c[w] & 0xffffff
-    print("slot", 6 + (w & 1), "heaviest: point", idx, "passes", passes, "s", s[idx], "theta", th[idx], "params", [float(p[idx]) for p in params],
-          "value", out[idx].cpu().numpy()[6:], "status", st[idx].cpu().numpy()[6:])
+batches, idx = c[15] >> 24, c[15] & 0xffffff
+print("heaviest task: point", idx, "batches", batches, "s", s[idx], "theta", th[idx], "params", [float(p[idx]) for p in params],
+      "value", out[idx].cpu().numpy()[6:], "status", st[idx].cpu().numpy()[6:])
+print("shared batches", c[8], "helper reqs", c[9], "owner shared reqs", c[10], "owner wait ms", c[11] / 1e5, "eval us/req", c[14] / 100. / max(c[7], 1))
