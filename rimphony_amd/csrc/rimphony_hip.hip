@@ -891,17 +891,22 @@ __global__ __launch_bounds__(64) void qag_selftest_kernel(size_t count, const in
     const IStore st = istore_carve(s_store, CAP_NORM, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
     __shared__ QagPark s_qpark;
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
-    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const int fam = family[i];
-        const double q0 = p0[i], q1 = p1[i];
-        auto f = [&](double x, bool active) -> double { return active ? selftest_integrand(fam, q0, q1, x) : 0.; };
-        QagState q;
-        wave_qag(f, g, st, a[i], b[i], epsabs, epsrel, limit, q, &s_qpark);
+    // problems 2j and 2j + 1 run as a pair (wave_qag_pair: shared first rule application), as the
+    // product kernels run their gamma-integrals; an odd last problem runs alone
+    for (size_t i = 2 * (size_t) blockIdx.x; i < count; i += 2 * (size_t) gridDim.x) {
+        const bool have1 = i + 1 < count;
+        const size_t i1 = have1 ? i + 1 : i;
+        const int fam0 = family[i], fam1 = family[i1];
+        const double q00 = p0[i], q01 = p1[i], q10 = p0[i1], q11 = p1[i1];
+        auto f = [&](double x, bool active, bool second) -> double {
+            return active ? selftest_integrand(second ? fam1 : fam0, second ? q10 : q00, second ? q11 : q01, x) : 0.;
+        };
+        double r0, r1, ae[2];
+        int s0, s1, sz[2];
+        wave_qag_pair(f, g, st, a[i], b[i], a[i1], b[i1], have1, false, epsabs, epsrel, limit, &s_qpark, r0, s0, r1, s1, ae, sz);
         if (g.lane == 0) {
-            result[i] = q.result;
-            abserr[i] = q.abserr;
-            qstatus[i] = q.status;
-            size[i] = q.size;
+            result[i] = r0; abserr[i] = ae[0]; qstatus[i] = s0; size[i] = sz[0];
+            if (have1) { result[i1] = r1; abserr[i1] = ae[1]; qstatus[i1] = s1; size[i1] = sz[1]; }
         }
     }
 }

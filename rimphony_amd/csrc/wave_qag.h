@@ -514,7 +514,8 @@ template <class F>
 __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStore &st,
                                               double a0, double b0, double a1, double b1, bool have1, bool flip,
                                               double epsabs, double epsrel, int limit, QagPark *park,
-                                              double &r0, int &qs0, double &r1, int &qs1)
+                                              double &r0, int &qs0, double &r1, int &qs1,
+                                              double *abserr_out = nullptr, int *size_out = nullptr)   // [2] each, optional
 {
     const int lane = g.lane;
     QagState q;
@@ -583,6 +584,8 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
         for (;;) {                   // integral `cur` is complete
             if (lane == 0) park->ctr.inner_qags += 1;
             if (cur == 0) { r0 = uni(q.result); qs0 = uni(q.status); } else { r1 = uni(q.result); qs1 = uni(q.status); }
+            if (abserr_out) abserr_out[cur] = q.abserr;
+            if (size_out) size_out[cur] = q.size;
             if (cur != 0 || !have1) return;
             cur = 1;                 // integral 1 continues from its parked first-rule result
             qag_begin(q, epsabs, epsrel, limit);
