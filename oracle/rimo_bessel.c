@@ -293,7 +293,7 @@ double rimo_bessel_j(const double n, const double x)
     logn = m_log10(n);
 
     if (x < n) {
-        const double eta = m_log10((n - x) / n);
+        const double eta = m_log10_region((n - x) / n);
         const double eta_thresh_lo = -0.6666666 * logn + MINUS_ETA_A_INTERCEPT;
         const double eta_thresh_hi = -0.6666666 * logn + MINUS_ETA_B_INTERCEPT;
 
@@ -308,7 +308,7 @@ double rimo_bessel_j(const double n, const double x)
             return debye * (1 - pos) + meissel1 * pos;
         }
     } else {
-        const double eta = m_log10((x - n) / x);
+        const double eta = m_log10_region((x - n) / x);
         const double eta_thresh_lo = -0.6666666 * logn + PLUS_ETA_A_INTERCEPT;
         if (eta < eta_thresh_lo)
             return debye_eps_exp(n, x);

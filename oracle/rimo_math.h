@@ -12,6 +12,7 @@
 #define m_exp(x) exp(x)
 #define m_log(x) log(x)
 #define m_log10(x) log10(x)
+#define m_log10_region(x) log10(x)
 #define m_pow(x, y) pow(x, y)
 #define m_pow15(x) pow(x, 1.5)
 #define m_pow25(x) pow(x, 2.5)
@@ -22,6 +23,7 @@ static inline void m_sincos(double x, double *s, double *c) { *s = sin(x); *c = 
 #define m_exp(x) rim_exp(x)
 #define m_log(x) rim_log(x)
 #define m_log10(x) rim_log10(x)
+#define m_log10_region(x) rim_log10_region(x)
 #define m_pow(x, y) rim_pow(x, y)
 #define m_pow15(x) rim_pow15(x)
 #define m_pow25(x) rim_pow25(x)

@@ -210,6 +210,38 @@ RIM_FN double rim_log10(double x)
     return p + (e + rim_fma(hi, C_LO, lo * C_HI));
 }
 
+/* log10 of a positive, finite, normal x in plain double arithmetic (<= 4 ulp; tests/test_detmath.py).
+ * Used for the Bessel region variable eta = log10((n - x) / n) (bessel.c:341-357), which is only compared
+ * with thresholds and turned into a blend weight: the double-double tail of rim_log10 buys nothing there
+ * and costs a third of the function.  Oracle (deterministic build) and kernels share it. */
+RIM_FN double rim_log10_region(double x)
+{
+    uint64_t u = rim_bits(x);
+    int k = (int) (u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = rim_frombits(u);      /* [1, 2) */
+    if (m > 1.4142135623730951) { m = 0.5 * m; k += 1; }   /* [0.7071, 1.4142] */
+    const double f = m - 1.0;        /* exact */
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    /* atanh(s)/s - 1 = z/3 + z^2/5 + ... + z^11/23 */
+    double q = 1.0 / 23.0;
+    q = rim_fma_k(q, z, 1.0 / 21.0);
+    q = rim_fma_k(q, z, 1.0 / 19.0);
+    q = rim_fma_k(q, z, 1.0 / 17.0);
+    q = rim_fma_k(q, z, 1.0 / 15.0);
+    q = rim_fma_k(q, z, 1.0 / 13.0);
+    q = rim_fma_k(q, z, 1.0 / 11.0);
+    q = rim_fma_k(q, z, 1.0 / 9.0);
+    q = rim_fma_k(q, z, 1.0 / 7.0);
+    q = rim_fma_k(q, z, 1.0 / 5.0);
+    q = rim_fma_k(q, z, 1.0 / 3.0);
+    const double a = 2.0 * s;
+    const double ln_m = rim_fma(a, q * z, a);                       /* ln m = 2 s (1 + q z) */
+    /* k log10(2) + ln(m) / ln(10) */
+    return rim_fma((double) k, 0.30102999566398120, ln_m * 0.43429448190325182);
+}
+
 /* ---- pow ------------------------------------------------------------- */
 
 RIM_FN double rim_pow(double x, double y)

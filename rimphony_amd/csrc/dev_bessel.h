@@ -298,7 +298,7 @@ RIM_DEV double leung_j(const LeungOrder &o, double x)
         if (r < o.r_lo_dn) { need_debye = true; need_meissel = false; }
         else if (r > o.r_hi_up) { need_debye = false; need_meissel = true; }
         else {
-            const double eta = rim_log10(r);
+            const double eta = rim_log10_region(r);
             if (eta < o.thr_lo) { need_debye = true; need_meissel = false; }
             else if (eta > o.thr_hi) { need_debye = false; need_meissel = true; }
             else {
@@ -312,7 +312,7 @@ RIM_DEV double leung_j(const LeungOrder &o, double x)
         if (r < o.rp_dn) need_debye = true;
         else if (r > o.rp_up) { need_debye = false; unsupported = true; }   // Meissel "second" region: off the hot path
         else {
-            const double eta = rim_log10(r);
+            const double eta = rim_log10_region(r);
             if (eta < o.thr_plus_lo) need_debye = true;
             else { need_debye = false; unsupported = true; }
         }

@@ -24,6 +24,7 @@ double t_cos(double x){double s,c;rim_sincos(x,&s,&c);return c;}
 long t_div_by_mismatches(const double *a, const double *b, long n)
 { long bad = 0; for (long i = 0; i < n; i++) { if (rim_div_by(a[i], b[i], 1.0 / b[i]) != a[i] / b[i]) bad++; } return bad; }
 double t_pow15(double x){return rim_pow15(x);}
+double t_log10_region(double x){return rim_log10_region(x);}
 '''
 
 
@@ -120,3 +121,23 @@ def test_pow15(dm):
         ref = mp.mpf(float(x)) ** mp.mpf(1.5)
         got = dm.t_pow15(float(x))
         assert abs((mp.mpf(got) - ref) / ref) < 3e-16
+
+
+def test_log10_region(dm):
+    """The plain-double log10 of the Bessel region variable: a few ulp (<= 4) on (0, 1], its whole domain."""
+    dm.t_log10_region.restype = ctypes.c_double
+    dm.t_log10_region.argtypes = [ctypes.c_double]
+    mp.mp.prec = 200
+    rng = np.random.default_rng(8)
+    xs = np.concatenate([np.exp(rng.uniform(math.log(1e-16), 0., 4000)), 1. - np.exp(rng.uniform(math.log(1e-16), math.log(0.5), 1000)),
+                         [1.0, 0.5, 0.70710678118654752, 0.7071067811865476]])
+    worst = 0.
+    for x in xs:
+        ref = mp.log10(mp.mpf(float(x)))
+        got = dm.t_log10_region(float(x))
+        if ref == 0:
+            assert got == 0.
+            continue
+        ulp = abs(float(np.spacing(float(ref))))
+        worst = max(worst, float(abs(mp.mpf(got) - ref)) / ulp)
+    assert worst <= 4.0, worst
