@@ -125,6 +125,21 @@ class Context:
             return out.cpu().numpy(), st.cpu().numpy()
         return out.cpu().numpy()
 
+    DETMATH_OPS = {"exp": 0, "log": 1, "log10": 2, "pow": 3, "sqrt": 4, "log10_region": 5, "lgamma": 6, "sin": 7, "cos": 8,
+                   "div_by": 9}
+
+    def detmath_batch(self, op, x, y=None):
+        """Unit seam: a leaf function of detmath.h evaluated on the device over host arrays."""
+        dx = self._as_dev(x)
+        dy = self._as_dev(y) if y is not None else None
+        out = torch.empty_like(dx)
+        capi.check(self.lib.rimphony_detmath_batch_device(
+            self.handle, self.DETMATH_OPS[op], dx.numel(), ctypes.c_void_p(dx.data_ptr()),
+            ctypes.c_void_p(dy.data_ptr()) if dy is not None else None, ctypes.c_void_p(out.data_ptr()), self._stream()),
+            "rimphony_detmath_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def highfreq_batch(self, kind, s, theta, params):
         """High-frequency closed forms (power law / thermal only): host arrays in, [n, 2] = {rho_Q, rho_V} out."""
         ds, dth = self._as_dev(s), self._as_dev(theta)

@@ -1510,6 +1510,41 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     return RIMPHONY_OK;
 }
 
+// ---- unit seam for the leaf functions of detmath.h ------------------------------------------
+__global__ void detmath_kernel(int op, size_t n, const double *x, const double *y, double *out)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y ? y[i] : 0.;
+    double r, t;
+    switch (op) {
+    case 0: r = rim_exp(a); break;
+    case 1: r = rim_log(a); break;
+    case 2: r = rim_log10(a); break;
+    case 3: r = rim_pow(a, b); break;
+    case 4: r = rim_sqrt(a); break;
+    case 5: r = rim_log10_region(a); break;
+    case 6: r = rim_lgamma_pos(a); break;
+    case 7: rim_sincos(a, &r, &t); break;
+    case 8: rim_sincos(a, &t, &r); break;
+    case 9: r = rim_div_by(a, b, 1. / b); break;
+    default: r = RIM_NAN; break;
+    }
+    out[i] = r;
+}
+
+extern "C" int rimphony_detmath_batch_device(rimphony_ctx *c, int op, size_t n, const double *d_x, const double *d_y,
+                                             double *d_out, void *stream)
+{
+    if (!c || op < 0 || op > 9) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;
+    if (!d_x || !d_out || ((op == 3 || op == 9) && !d_y)) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(detmath_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, op, n, d_x, d_y, d_out);
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
 // ---- high-frequency closed forms ---------------------------------------------
 __global__ void highfreq_kernel(int kind, size_t n, const double *s, const double *theta, const double *p0,
                                 const double *p1, double *out)
