@@ -80,6 +80,30 @@ RIM_FN double rim_div_by(double a, double b, double binv)
     return rim_fma(r, binv, q);
 }
 
+/* num / den for operands of moderate magnitude.  hipcc expands an fp64 division into v_div_scale (x2), v_rcp,
+ * two Newton steps, a quotient, its residual, v_div_fmas and v_div_fixup: 11 VALU issues.  The scale / fixup
+ * instructions only act when an operand is zero, infinite, NaN or subnormal, or when the exponents are within
+ * a few binades of the range limits; otherwise they pass their inputs through and the quotient is the result
+ * of the 8 arithmetic instructions, which this function issues bare.  It is therefore bit-identical to `/`
+ * whenever num, den and num / den are normal numbers far from the range limits (and NaN in, NaN out) -- it is
+ * used only where that is certain by construction (each call site says why), never on Bessel values or
+ * quadrature sums, which do underflow. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rim_div_moderate(double num, double den)
+{
+    double y = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-den, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = num * y;
+    const double r = __builtin_fma(-den, q, num);
+    return __builtin_fma(r, y, q);
+}
+#else
+RIM_FN double rim_div_moderate(double num, double den) { return num / den; }
+#endif
+
 /* sqrt.  On the device hipcc expands __builtin_sqrt into v_rsq_f64 + a Goldschmidt/Newton sequence wrapped in
  * input scaling (applied when x < 2^-767) and special-value selects: 18 VALU issues per call, ~8 calls per
  * integrand sample.  The bare sequence below is that same expansion without the scaling (13 issues): it returns
@@ -183,7 +207,7 @@ RIM_FN double rim_log_dd(double x, double *lo)
     /* s = f / (2 + f) in double-double */
     const double th = 2.0 + f;
     const double tl = (2.0 - th) + f;            /* exact (Fast2Sum, 2 >= |f|) */
-    const double rcp = 1.0 / th;
+    const double rcp = rim_div_moderate(1.0, th);     /* th in [1.70, 2.42] */
     const double sh = f * rcp;
     double res = rim_fma(-sh, th, f);
     res = rim_fma(-sh, tl, res);
@@ -249,7 +273,7 @@ RIM_FN double rim_log10_region(double x)
     double m = rim_frombits(u);      /* [1, 2) */
     if (m > 1.4142135623730951) { m = 0.5 * m; k += 1; }   /* [0.7071, 1.4142] */
     const double f = m - 1.0;        /* exact */
-    const double s = f / (2.0 + f);
+    const double s = rim_div_moderate(f, 2.0 + f);    /* |f| <= 0.42 (f = 0 gives 0 either way), 2 + f in [1.70, 2.42] */
     const double z = s * s;
     /* atanh(s)/s - 1 = z/3 + z^2/5 + ... + z^11/23 */
     double q = 1.0 / 23.0;

@@ -127,7 +127,8 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     const double z = rim_div_by(x, n, o.ninv);
     const double eps = rim_div_by(n - x, n, o.ninv);
     const double Z = rim_sqrt(eps * (1 + z));
-    const double U = 1. / (n * Z * Z * Z);
+    // Z = sqrt(eps (1 + z)) with eps in [2^-53, 1) (x < n here): 1e-8 < Z < 1.42, n < 1e15 -> moderate operands
+    const double U = rim_div_moderate(1., n * Z * Z * Z);
     const double t = z * z;
 
     double a7, a6, a5, a4, a3, a2, a1, a0;
@@ -178,7 +179,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     v = rim_fma(v, U, a0);
     const double vsum1 = rim_div_by(U * v, 0.10321920e8, 1. / 0.10321920e8);
 
-    const double factor = 1. / (o.np1 * rim_sqrt(Z));
+    const double factor = rim_div_moderate(1., o.np1 * rim_sqrt(Z));
 
     double exp_val;
     if (eps < 1e-4 && o.big_n) {
@@ -202,7 +203,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
             q = rim_fma_k(q, Z, 1.);
             invZp1 = q;
         } else {
-            invZp1 = 1. / (1. + Z);
+            invZp1 = rim_div_moderate(1., 1. + Z);
         }
         RIM_PROF_T(t_ml);
         exp_val = n * (rim_log(x * invZp1) - (1 - Z)) - vsum1 - o.vsum2 - o.lgam;
