@@ -53,7 +53,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
 {
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
-        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
         return d.norm * rim_pow(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
     } else if (KIND == DIST_THERMAL_JUETTNER) {
         return d.norm * rim_exp(d.neg_inverse_t * gamma);
@@ -61,7 +61,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
         if (gamma < d.par[2] || gamma > d.par[3]) return 0.;
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, d.par[1]);
-        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
         const double gamma_term = rim_pow(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term / (gamma * gamma * beta);
     } else {
@@ -92,7 +92,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double p = d.par[0], k = d.par[1];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, k);
-        const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+        const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
         const double gamma_term = rim_pow(gamma, -p) * rim_exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
         dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
@@ -192,7 +192,7 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     const double s = pt.s, n = so.n;
     const double cos_th = pt.cos_th, sin_th = pt.sin_th;
 
-    const double beta = rim_sqrt(1. - 1. / (gamma * gamma));
+    const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
     const double cos_xi = (s * gamma - n) / (s * gamma * beta * cos_th);
     const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
     const double m = (cos_th - beta * cos_xi) / sin_th;
@@ -204,9 +204,9 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     } else {
         const double bc = beta * cos_th;
         const double beta2_costh2 = bc * bc;
-        const double s_on_r = 2. * n / (s * (beta2_costh2 - 1.));
-        const double r = 1. - 1. / beta2_costh2;
-        gamma_sin_xi = rim_sqrt(r * (gamma * (gamma + s_on_r)) - (n * n / (s * s * beta2_costh2)));
+        const double s_on_r = rim_div_moderate(2. * n, s * (beta2_costh2 - 1.));
+        const double r = 1. - rim_div_moderate(1., beta2_costh2);
+        gamma_sin_xi = rim_sqrt(r * (gamma * (gamma + s_on_r)) - rim_div_moderate(n * n, s * s * beta2_costh2));
     }
 
     const double z = s * beta * sin_th * gamma_sin_xi;
