@@ -343,6 +343,20 @@ RIM_FN double rim_pow15(double x) { return x * rim_sqrt(x); }
 /* x^2.5 as x^2 * sqrt(x) (three roundings) */
 RIM_FN double rim_pow25(double x) { return (x * x) * rim_sqrt(x); }
 
+/* rim_pow(x, y) for a positive, finite x and a finite y: the same three steps (double-double log, product,
+ * exp of the sum) without the dozen special-case tests in front of them, hence the same bits on that domain
+ * (x = 1 and y = 0 still give exactly 1: log 1 = 0 and exp 0 = 1 are exact here).  tests/test_detmath.py. */
+RIM_FN double rim_pow_pos(double x, double y)
+{
+    double ll;
+    const double lh = rim_log_dd(x, &ll);
+    const double ph = y * lh;
+    const double pl = rim_fma(y, lh, -ph) + y * ll;
+    if (ph > 800.0) return RIM_INF;
+    if (ph < -800.0) return 0.0;
+    return rim_exp_dd(ph, pl);
+}
+
 /* ---- lgamma (positive arguments only) --------------------------------- */
 
 /* Stirling series for x >= 16 (error of the truncated series < 1e-19 rel). */
