@@ -80,13 +80,13 @@ RIM_DEV double ascending_series_tab(const double *row, double q, double sign)
 RIM_DEV double bessel_i_g(int j, double gam, const double *tab, double x)
 {
     const double h = 0.5 * x;
-    return rim_pow(h, hey_series_order(j)) / gam * ascending_series_tab(tab + j * RIM_SERIES_ROW, h * h, 1.);
+    return rim_pow_pos(h, hey_series_order(j)) / gam * ascending_series_tab(tab + j * RIM_SERIES_ROW, h * h, 1.);
 }
 
 RIM_DEV double bessel_jnu(double nu, double x)
 {
     const double h = 0.5 * x;
-    return rim_pow(h, nu) / gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);
+    return rim_pow_pos(h, nu) / gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);   // h >= 0 (x = sqrt(..))
 }
 
 RIM_DEV double bessel_ynu(double nu, double x)
