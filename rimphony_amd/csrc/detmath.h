@@ -246,6 +246,60 @@ RIM_FN double rim_log_dd(double x, double *lo)
     return hi;
 }
 
+/* The same for a positive, finite, NORMAL x (no special values, no subnormal rescaling): identical bits there. */
+RIM_FN double rim_log_dd_normal(double x, double *lo)
+{
+    int k = 0;
+    uint64_t u = rim_bits(x);
+    k += (int) (u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = rim_frombits(u);      /* [1, 2) */
+    if (m > 1.4142135623730951) { m = 0.5 * m; k += 1; }   /* [0.7071, 1.4142] */
+
+    const double f = m - 1.0;        /* exact */
+    /* s = f / (2 + f) in double-double */
+    const double th = 2.0 + f;
+    const double tl = (2.0 - th) + f;            /* exact (Fast2Sum, 2 >= |f|) */
+    const double rcp = rim_div_moderate(1.0, th);     /* th in [1.70, 2.42] */
+    const double sh = f * rcp;
+    double res = rim_fma(-sh, th, f);
+    res = rim_fma(-sh, tl, res);
+    const double sl = res * rcp;
+
+    /* atanh(s)/s - 1 = z/3 + z^2/5 + ... + z^11/23,  z = s^2 <= 0.0295 */
+    const double z = sh * sh;
+    double q = 1.0 / 23.0;
+    q = rim_fma_k(q, z, 1.0 / 21.0);
+    q = rim_fma_k(q, z, 1.0 / 19.0);
+    q = rim_fma_k(q, z, 1.0 / 17.0);
+    q = rim_fma_k(q, z, 1.0 / 15.0);
+    q = rim_fma_k(q, z, 1.0 / 13.0);
+    q = rim_fma_k(q, z, 1.0 / 11.0);
+    q = rim_fma_k(q, z, 1.0 / 9.0);
+    q = rim_fma_k(q, z, 1.0 / 7.0);
+    q = rim_fma_k(q, z, 1.0 / 5.0);
+    q = rim_fma_k(q, z, 1.0 / 3.0);
+    q = q * z;
+
+    /* log m = 2 sh + (2 sl + 2 sh q) */
+    const double a = 2.0 * sh;
+    const double c = rim_fma(a, q, 2.0 * sl);
+
+    /* + k ln2, ln2 = LN2_HI + LN2_LO with k*LN2_HI exact */
+    const double kd = (double) k;
+    const double kh = kd * 6.93147180369123816490e-01;
+    const double kl = kd * 1.90821492927058770002e-10;
+    /* TwoSum(kh, a) */
+    const double s1 = kh + a;
+    const double bb = s1 - kh;
+    const double e1 = (kh - (s1 - bb)) + (a - bb);
+    const double low = e1 + (c + kl);
+    const double hi = s1 + low;
+    *lo = (s1 - hi) + low;
+    return hi;
+}
+
+
 RIM_FN double rim_log(double x) { double lo; return rim_log_dd(x, &lo); }
 
 RIM_FN double rim_log10(double x)
@@ -350,6 +404,18 @@ RIM_FN double rim_pow_pos(double x, double y)
 {
     double ll;
     const double lh = rim_log_dd(x, &ll);
+    const double ph = y * lh;
+    const double pl = rim_fma(y, lh, -ph) + y * ll;
+    if (ph > 800.0) return RIM_INF;
+    if (ph < -800.0) return 0.0;
+    return rim_exp_dd(ph, pl);
+}
+
+/* ... and for a positive NORMAL finite x (no zero, subnormal, infinity or NaN to look for). */
+RIM_FN double rim_pow_normal(double x, double y)
+{
+    double ll;
+    const double lh = rim_log_dd_normal(x, &ll);
     const double ph = y * lh;
     const double pl = rim_fma(y, lh, -ph) + y * ll;
     if (ph > 800.0) return RIM_INF;

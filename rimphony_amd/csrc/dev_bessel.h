@@ -222,7 +222,7 @@ RIM_DEV double debye_eps(double n, double x)
 
     const double ez = x - n;
     RIM_PROF_T(t_dp);
-    const double z = rim_pow_pos(x, 1. / 3.);      // x > 0: the Debye band lies next to x = n >= 30
+    const double z = rim_pow_normal(x, 1. / 3.);      // x > 0: the Debye band lies next to x = n >= 30
     RIM_PROF_ADD(17, t_dp);
     const double t3 = z * z;
     const double t4 = x * z;

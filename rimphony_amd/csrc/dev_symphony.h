@@ -54,7 +54,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        return d.norm * rim_pow_pos(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
+        return d.norm * rim_pow_normal(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
     } else if (KIND == DIST_THERMAL_JUETTNER) {
         return d.norm * rim_exp(d.neg_inverse_t * gamma);
     } else if (KIND == DIST_PITCHY_PL) {
@@ -62,12 +62,12 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, d.par[1]);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = rim_pow_pos(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = rim_pow_normal(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term / (gamma * gamma * beta);
     } else {
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, d.par[2]);
-        const double gamma_term = rim_pow_pos(1. + (gamma - 1.) * d.inv_kappa_width, -(d.par[0] + 1.)) *
+        const double gamma_term = rim_pow_normal(1. + (gamma - 1.) * d.inv_kappa_width, -(d.par[0] + 1.)) *
             rim_exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term;
     }
@@ -80,7 +80,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         if (gamma < d.par[1] || gamma > d.par[2]) { dfdg = 0.; dfdcx = 0.; return; }
         const double p_plus_1 = d.par[0] + 1.;
         const double g2_minus_1 = gamma * gamma - 1.;
-        dfdg = -d.norm * rim_pow_pos(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
+        dfdg = -d.norm * rim_pow_normal(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
             rim_exp(-gamma * d.inv_gamma_cutoff) *
             (p_plus_1 / gamma + gamma / g2_minus_1 + d.inv_gamma_cutoff);
         dfdcx = 0.;
@@ -93,7 +93,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, k);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = rim_pow_pos(gamma, -p) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = rim_pow_normal(gamma, -p) * rim_exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
         dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
@@ -101,7 +101,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double kappa = d.par[0], width = d.par[1], k = d.par[2];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, k);
-        const double gamma_term = rim_pow_pos(1. + (gamma - 1.) * d.inv_kappa_width, -(kappa + 1.)) *
+        const double gamma_term = rim_pow_normal(1. + (gamma - 1.) * d.inv_kappa_width, -(kappa + 1.)) *
             rim_exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term;
         dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);

@@ -27,6 +27,7 @@ double t_pow15(double x){return rim_pow15(x);}
 double t_log10_region(double x){return rim_log10_region(x);}
 double t_sqrt(double x){return rim_sqrt(x);}
 double t_pow_pos(double x,double y){return rim_pow_pos(x,y);}
+double t_pow_normal(double x,double y){return rim_pow_normal(x,y);}
 double t_div_by(double a,double b){return rim_div_by(a,b,1.0/b);}
 '''
 
@@ -196,11 +197,14 @@ def test_leaf_functions_same_bits_on_gpu(dm):
 
 
 def test_pow_pos_is_pow_on_its_domain(dm):
-    dm.t_pow_pos.restype = ctypes.c_double
-    dm.t_pow_pos.argtypes = [ctypes.c_double] * 2
+    for f in (dm.t_pow_pos, dm.t_pow_normal):
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_double] * 2
     rng = np.random.default_rng(9)
     xs = np.concatenate([np.exp(rng.uniform(-700., 700., 20000)), [1., 1., 2., 1e-310, 5e-324]])
     ys = np.concatenate([rng.uniform(-12., 12., 20000), [3.3, 0., 0., 0.5, 0.3333333333333333]])
     for x, y in zip(xs, ys):
         a, b = dm.t_pow_pos(float(x), float(y)), dm.t_pow(float(x), float(y))
         assert a == b or (math.isnan(a) and math.isnan(b)), (x, y, a, b)
+        if x >= 2.2250738585072014e-308:          # rim_pow_normal: positive normal bases only
+            assert dm.t_pow_normal(float(x), float(y)) == b, (x, y)
