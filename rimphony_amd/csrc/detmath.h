@@ -145,12 +145,9 @@ RIM_FN double rim_ldexp(double x, int k) { return __builtin_ldexp(x, k); }
 /* ---- exp ------------------------------------------------------------- */
 
 /* exp(xh + xl) for |xl| << |xh|; one ulp class accuracy (< 0.6 ulp). */
-RIM_FN double rim_exp_dd(double xh, double xl)
+/* exp(xh + xl) for |xh| <= 700 (no NaN, overflow or underflow to look for): the arithmetic of rim_exp_dd. */
+RIM_FN double rim_exp_dd_core(double xh, double xl)
 {
-    if (rim_isnan(xh)) return xh;
-    if (xh > 709.782712893384) return RIM_INF;
-    if (xh < -745.2) return 0.0;
-
     /* k = nearest integer to x / ln 2 */
     const double kd = __builtin_rint(xh * 1.44269504088896338700e+00);
     const int k = (int) kd;
@@ -177,7 +174,19 @@ RIM_FN double rim_exp_dd(double xh, double xl)
     return rim_ldexp(p, k);
 }
 
+
+RIM_FN double rim_exp_dd(double xh, double xl)
+{
+    if (rim_isnan(xh)) return xh;
+    if (xh > 709.782712893384) return RIM_INF;
+    if (xh < -745.2) return 0.0;
+
+    return rim_exp_dd_core(xh, xl);
+}
+
 RIM_FN double rim_exp(double x) { return rim_exp_dd(x, 0.0); }
+/* exp(x) for |x| <= 700: same bits as rim_exp there */
+RIM_FN double rim_exp_bounded(double x) { return rim_exp_dd_core(x, 0.0); }
 
 /* ---- log ------------------------------------------------------------- */
 
@@ -418,9 +427,10 @@ RIM_FN double rim_pow_normal(double x, double y)
     const double lh = rim_log_dd_normal(x, &ll);
     const double ph = y * lh;
     const double pl = rim_fma(y, lh, -ph) + y * ll;
-    if (ph > 800.0) return RIM_INF;
-    if (ph < -800.0) return 0.0;
-    return rim_exp_dd(ph, pl);
+    /* rim_pow's two range tests and rim_exp_dd's own two collapse into these (same outcome for every ph) */
+    if (ph > 709.782712893384) return RIM_INF;
+    if (ph < -745.2) return 0.0;
+    return rim_exp_dd_core(ph, pl);
 }
 
 /* ---- lgamma (positive arguments only) --------------------------------- */

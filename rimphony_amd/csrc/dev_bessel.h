@@ -64,7 +64,7 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
         if (log_f * f_exp < 0.) return sign_f * rim_exp(log_f + f_exp);
         return f_factor * rim_exp(f_exp);
     }
-    return f_factor * rim_exp(f_exp);
+    return f_factor * rim_exp_bounded(f_exp);      // 1e-3 <= |f_exp| <= 690 here (or NaN, which stays NaN)
 }
 
 // 10^t to single precision (relative error ~1e-6; only ever used behind a 1e-3 guard band, so the
