@@ -310,6 +310,9 @@ RIM_FN double rim_log_dd_normal(double x, double *lo)
 
 
 RIM_FN double rim_log(double x) { double lo; return rim_log_dd(x, &lo); }
+/* log of a positive normal finite x (same bits as rim_log there; for +0 and subnormals it returns about -709.1
+ * instead of -inf / the true value -- see the one call site for why that is harmless there) */
+RIM_FN double rim_log_normal(double x) { double lo; return rim_log_dd_normal(x, &lo); }
 
 RIM_FN double rim_log10(double x)
 {

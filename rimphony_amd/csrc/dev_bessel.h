@@ -206,7 +206,10 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
             invZp1 = rim_div_moderate(1., 1. + Z);
         }
         RIM_PROF_T(t_ml);
-        exp_val = n * (rim_log(x * invZp1) - (1 - Z)) - vsum1 - o.vsum2 - o.lgam;
+        // x * invZp1 is a positive normal number except for x = +0 or a subnormal x; there rim_log_normal gives
+        // about -709 instead of -inf / -720, and either way n >= 30 makes exp_val < -2e4: exp_factor returns
+        // f_factor * 0 in both cases, so the value of J is the same
+        exp_val = n * (rim_log_normal(x * invZp1) - (1 - Z)) - vsum1 - o.vsum2 - o.lgam;
         RIM_PROF_ADD(15, t_ml);
     }
     RIM_PROF_T(t_me);
