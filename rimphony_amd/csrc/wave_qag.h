@@ -545,7 +545,12 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
         const double hl = 0.5 * (lb - la);
         const double x = 0.5 * (la + lb) + hl * g.t;
         if (lane == 0) {
-            park->q = q;
+            // only what is live across the integrand (qag_uniformize_live reads exactly these back)
+            QagState &pq = park->q;
+            pq.area = q.area; pq.errsum = q.errsum; pq.tolerance = q.tolerance;
+            pq.iteration = q.iteration; pq.rt1 = q.rt1; pq.rt2 = q.rt2;
+            pq.error_type = q.error_type; pq.size = q.size; pq.imax = q.imax;
+            pq.a1 = q.a1; pq.b1 = q.b1; pq.a2 = q.a2; pq.b2 = q.b2; pq.r_i = q.r_i; pq.e_i = q.e_i;
             park->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
             park->ctr.steps += 1;
             if (park->hb) {
