@@ -41,7 +41,9 @@ RIM_DEV double ascending_series(double nu, double q, double sign)
 {
     double term = 1., sum = 1.;
     for (int k = 1; k <= 500; k++) {
-        term = term * (sign * q / (k * (k + nu)));
+        // q = (x/2)^2 and k (k + nu) are normal numbers of moderate size (a negative order is never an exact
+        // integer here: bessel_ynu perturbs those) -> the bare division is exact (detmath.h)
+        term = term * rim_div_moderate(sign * q, k * (k + nu));
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
     }
