@@ -86,7 +86,10 @@ int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unkno
 typedef struct rimphony_ctx rimphony_ctx;
 
 /* Create / destroy a context bound to one HIP device.  Fails with
- * RIMPHONY_ENODEVICE when no GPU is present (there is no CPU fallback). */
+ * RIMPHONY_ENODEVICE when no GPU is present (there is no CPU fallback).
+ * Environment, read once here: RIMPHONY_NO_ASSIST=1 turns the cooperative tail of the kernels off (one
+ * wavefront per task to the end; same results bit for bit, used for A/B measurements and by the tests).
+ * A context assumes it has the GPU to itself: its persistent grids fill the device. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);
 void rimphony_ctx_destroy(rimphony_ctx *ctx);
 const char *rimphony_strerror(int code);
