@@ -282,3 +282,25 @@ def test_cooperative_tail_changes_no_bit(gpu_ctx):
     solo_ctx.close()
     assert same_bits(coop, solo).all()
     assert (st_coop == st_solo).all()
+
+
+def test_api_misuse_is_an_error_code_not_a_crash(gpu_ctx):
+    """Error convention of the boundary: negative return on misuse, never an abort."""
+    import ctypes
+    from rimphony_amd import capi
+    lib = capi.load()
+    h = gpu_ctx.handle
+    one = (ctypes.c_double * 1)(1.0)
+    pp = (ctypes.c_void_p * 4)(None, None, None, None)
+    out = (ctypes.c_double * 8)()
+    # distribution kind out of range, null arrays, null context
+    assert lib.rimphony_batch_compute_device(h, 7, 1, one, one, pp, 0xFF, out, None, None) < 0
+    assert lib.rimphony_batch_compute_device(h, 0, 1, None, None, pp, 0xFF, out, None, None) < 0
+    assert lib.rimphony_batch_compute_device(None, 0, 1, one, one, pp, 0xFF, out, None, None) < 0
+    assert lib.rimphony_highfreq_batch_device(h, 2, 1, one, one, pp, out, None) < 0        # no HF form for pitchy_pl
+    assert lib.rimphony_dist_nparams(-1) < 0
+    lib.rimphony_strerror.restype = ctypes.c_char_p
+    assert lib.rimphony_strerror(-1) and lib.rimphony_strerror(-4)
+    # the context is still usable afterwards
+    got = gpu_ctx.compute_batch(0, [10.0], [0.8], [[2.5], [1.0], [1e12], [1e10]], 0x03)
+    assert np.isfinite(got[0, :2]).all()
