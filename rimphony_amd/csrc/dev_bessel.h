@@ -284,54 +284,166 @@ RIM_DEV double debye_eps(double n, double x)
     return p / (RIM_PI * t146 * 0.58354968672000000e17);
 }
 
-// pkgw_bessel_j for n >= 30 given the hoisted order data.  The region logic of
-// bessel.c:336-375 is folded into two flags so that each expansion has a single
-// (inlined) call site; a wave whose lanes straddle a region boundary executes
-// both bodies under exec masks, which is also what the blend zone needs.
-RIM_DEV double leung_j(const LeungOrder &o, double x)
+// The same for two orders at one x (J_n and J_{n+1} of a sample): everything except ez = x - n -- the cube root
+// and the thirteen coefficient polynomials in x^(1/3) -- is shared, each coefficient being consumed by both
+// Horner recurrences as soon as it is formed (two accumulators live instead of thirteen hoisted coefficients).
+// Per order the operations and their order are those of debye_eps.
+RIM_DEV void debye_eps_pair(double n0, double n1, double x, double *r0, double *r1)
+{
+    if (x > 1.e55) { *r0 = RIM_NAN; *r1 = RIM_NAN; return; }
+
+    const double ez0 = x - n0, ez1 = x - n1;
+    RIM_PROF_T(t_dp);
+    const double z = rim_pow_normal(x, 1. / 3.);      // x > 0: the Debye band lies next to x = n >= 30
+    RIM_PROF_ADD(17, t_dp);
+    const double t3 = z * z;
+    const double t4 = x * z;
+    const double t10 = t4 * t4;
+    const double t146 = t10 * t10;
+    const double K38 = 810485676000000. * RIM_AT4;
+
+    double q, c, p0, p1;
+    // innermost first: d13, then d12 .. d0 folded into the running Horner value
+    c = rim_fma_k(3123750. * RIM_AT13, t3, -833000. * RIM_AT15);
+    p0 = rim_fma(14875. * RIM_AT15, ez0 * ez0, c);
+    p1 = rim_fma(14875. * RIM_AT15, ez1 * ez1, c);
+    c = (40608750. * RIM_AT12) * x;                                       // d12
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    c = rim_fma_k(-113704500. * RIM_AT13, t3, 17481100. * RIM_AT15);        // d11
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(5360355000. * RIM_AT10, t3, -1161410250. * RIM_AT12);
+    c = q * x;                                                            // d10
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = 53603550000. * RIM_AT9;
+    q = rim_fma_k(q, t4, 1474097625. * RIM_AT13);
+    c = rim_fma_k(q, t3, -173573400. * RIM_AT15);                           // d9
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(-88445857500. * RIM_AT10, t3, 11448186750. * RIM_AT12);
+    c = q * x;                                                            // d8
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(3859455600000. * RIM_AT7, t3, -643242600000. * RIM_AT9);
+    q = rim_fma_k(q, t4, -8397889500. * RIM_AT13);
+    c = rim_fma_k(q, t3, 849093050. * RIM_AT15);                            // d7
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = 27016189200000. * RIM_AT6;
+    q = rim_fma_k(q, t4, 459918459000. * RIM_AT10);
+    q = rim_fma_k(q, t3, -47153256150. * RIM_AT12);
+    c = q * x;                                                            // d6
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(-21612951360000. * RIM_AT7, t3, 2283511230000. * RIM_AT9);
+    q = rim_fma_k(q, t4, 20997160275. * RIM_AT13);
+    c = rim_fma_k(q, t3, -1938419560. * RIM_AT15);                          // d5
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(K38, t3, -94556662200000. * RIM_AT6);
+    q = rim_fma_k(q, t4, -860873013000. * RIM_AT10);
+    q = rim_fma_k(q, t3, 78248884350. * RIM_AT12);
+    c = q * x;                                                            // d4
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = 3241942704000000. * RIM_AT3;
+    q = rim_fma_k(q, t4, 29331862560000. * RIM_AT7);
+    q = rim_fma_k(q, t3, -2594411820000. * RIM_AT9);
+    q = rim_fma_k(q, t4, -19964735910. * RIM_AT13);
+    c = rim_fma_k(q, t3, 1748257220. * RIM_AT15);                           // d3
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = rim_fma_k(-K38, t3, 67540473000000. * RIM_AT6);
+    q = rim_fma_k(q, t4, 484040056500. * RIM_AT10);
+    q = rim_fma_k(q, t3, -41423013450. * RIM_AT12);
+    c = q * x;                                                            // d2
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = 19451656224000000. * RIM_AT1;
+    q = rim_fma_k(q, t3, -1296777081600000. * RIM_AT3);
+    q = rim_fma_k(q, t4, -8027667648000. * RIM_AT7);
+    q = rim_fma_k(q, t3, 8027667648000. * RIM_AT9);
+    q = rim_fma_k(q, z, -36011689560. * RIM_AT10);
+    q = rim_fma_k(q, t3, 3012121710. * RIM_AT12);
+    q = rim_fma_k(q, z, 4707059994. * RIM_AT13);
+    c = rim_fma_k(q, t3, -401283384. * RIM_AT15);                           // d1
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+    q = 19451656224000000. * RIM_AT0;
+    q = rim_fma_k(q, t4, 69470200800000. * RIM_AT4);
+    q = rim_fma_k(q, t3, -5403237840000. * RIM_AT6);
+    c = q * t10 * z;                                                      // d0
+    p0 = rim_fma(p0, ez0, c);
+    p1 = rim_fma(p1, ez1, c);
+
+    const double den = RIM_PI * t146 * 0.58354968672000000e17;
+    *r0 = p0 / den;
+    *r1 = p1 / den;
+}
+
+// pkgw_bessel_j for n >= 30 given the hoisted order data, in three steps:
+//   leung_select    the region logic of bessel.c:336-375 -> which expansions this x needs
+//   debye_eps / meissel_first
+//   leung_combine   the value bessel.c would return (incl. the linear blend)
+// so that the integrand can run the Debye expansion of J_n and J_{n+1} together (debye_eps_pair).
+struct LeungSel {
+    bool need_debye, need_meissel, blend, unsupported, nan;
+    double pos;
+};
+
+RIM_DEV LeungSel leung_select(const LeungOrder &o, double x)
 {
     const double n = o.n;
-    if (!(x >= 0)) return RIM_NAN;
-    bool need_debye, need_meissel, blend = false, unsupported = false;
-    double pos = 0.;
-    RIM_PROF_T(t_sel);
+    LeungSel s;
+    s.need_debye = false; s.need_meissel = false; s.blend = false; s.unsupported = false; s.nan = false;
+    s.pos = 0.;
+    if (!(x >= 0)) { s.nan = true; return s; }
     if (x == n) {
-        need_debye = true; need_meissel = false;
+        s.need_debye = true;
     } else if (x < n) {
         const double r = rim_div_by(n - x, n, o.ninv);
-        if (r < o.r_lo_dn) { need_debye = true; need_meissel = false; }
-        else if (r > o.r_hi_up) { need_debye = false; need_meissel = true; }
+        if (r < o.r_lo_dn) s.need_debye = true;
+        else if (r > o.r_hi_up) s.need_meissel = true;
         else {
             const double eta = rim_log10_region(r);
-            if (eta < o.thr_lo) { need_debye = true; need_meissel = false; }
-            else if (eta > o.thr_hi) { need_debye = false; need_meissel = true; }
+            if (eta < o.thr_lo) s.need_debye = true;
+            else if (eta > o.thr_hi) s.need_meissel = true;
             else {
-                need_debye = true; need_meissel = true; blend = true;
-                pos = (eta - o.thr_lo) / (0.295966 - 0.174857);
+                s.need_debye = true; s.need_meissel = true; s.blend = true;
+                s.pos = (eta - o.thr_lo) / (0.295966 - 0.174857);
             }
         }
     } else {
         const double r = (x - n) / x;
-        need_meissel = false;
-        if (r < o.rp_dn) need_debye = true;
-        else if (r > o.rp_up) { need_debye = false; unsupported = true; }   // Meissel "second" region: off the hot path
+        if (r < o.rp_dn) s.need_debye = true;
+        else if (r > o.rp_up) s.unsupported = true;      // Meissel "second" region: off the hot path
         else {
             const double eta = rim_log10_region(r);
-            if (eta < o.thr_plus_lo) need_debye = true;
-            else { need_debye = false; unsupported = true; }
+            if (eta < o.thr_plus_lo) s.need_debye = true;
+            else s.unsupported = true;
         }
     }
+    return s;
+}
+
+RIM_DEV double leung_combine(const LeungSel &s, double debye, double meissel1)
+{
+    if (s.nan || s.unsupported) return RIM_NAN;
+    if (s.blend) return debye * (1 - s.pos) + meissel1 * s.pos;
+    return s.need_debye ? debye : meissel1;
+}
+
+// Scalar form: a wave whose lanes straddle a region boundary executes both bodies under exec masks,
+// which is also what the blend zone needs.
+RIM_DEV double leung_j(const LeungOrder &o, double x)
+{
+    const LeungSel s = leung_select(o, x);
     double debye = 0., meissel1 = 0.;
-    RIM_PROF_ADD(3, t_sel);
-    RIM_PROF_T(t_deb);
-    if (need_debye) debye = debye_eps(n, x);
-    RIM_PROF_ADD(4, t_deb);
-    RIM_PROF_T(t_mei);
-    if (need_meissel) meissel1 = meissel_first(o, x);
-    RIM_PROF_ADD(5, t_mei);
-    if (unsupported) return RIM_NAN;
-    if (blend) return debye * (1 - pos) + meissel1 * pos;
-    return need_debye ? debye : meissel1;
+    if (s.need_debye) debye = debye_eps(o.n, x);
+    if (s.need_meissel) meissel1 = meissel_first(o, x);
+    return leung_combine(s, debye, meissel1);
 }
 
 // ---- integer orders below 30 ----------------------------------------------
