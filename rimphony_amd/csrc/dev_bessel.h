@@ -131,52 +131,51 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     const double U = rim_div_moderate(1., n * Z * Z * Z);
     const double t = z * z;
 
-    double a7, a6, a5, a4, a3, a2, a1, a0;
-    a7 = rim_fma_k(59968440., t, 4450158720.);
-    a7 = rim_fma_k(a7, t, 38435160960.);
-    a7 = rim_fma_k(a7, t, 86387857920.);
-    a7 = rim_fma_k(a7, t, 60631119360.);
-    a7 = rim_fma_k(a7, t, 12841758720.);
-    a7 = rim_fma_k(a7, t, 625766400.);
-    a7 = rim_fma_k(a7, t, 2580480.);
-    a7 = rim_fma_k(a7, t, 0.);
-    a6 = rim_fma_k(-16907985., t, -954875250.);
-    a6 = rim_fma_k(a6, t, -5897669400.);
-    a6 = rim_fma_k(a6, t, -8653594320.);
-    a6 = rim_fma_k(a6, t, -3405435264.);
-    a6 = rim_fma_k(a6, t, -299351808.);
-    a6 = rim_fma_k(a6, t, -2644992.);
-    a6 = rim_fma_k(a6, t, 6144.);
-    a5 = rim_fma_k(5537280., t, 228049920.);
-    a5 = rim_fma_k(a5, t, 940423680.);
-    a5 = rim_fma_k(a5, t, 800163840.);
-    a5 = rim_fma_k(a5, t, 138700800.);
-    a5 = rim_fma_k(a5, t, 2580480.);
-    a5 = rim_fma_k(a5, t, 0.);
-    a4 = rim_fma_k(-2163168., t, -61254720.);
-    a4 = rim_fma_k(a4, t, -151828480.);
-    a4 = rim_fma_k(a4, t, -60518400.);
-    a4 = rim_fma_k(a4, t, -2519040.);
-    a4 = rim_fma_k(a4, t, -8192.);
-    a3 = rim_fma_k(-1048320., t, -18708480.);
-    a3 = rim_fma_k(a3, t, -23224320.);
-    a3 = rim_fma_k(a3, t, -2580480.);
-    a3 = rim_fma_k(a3, t, 0.);
-    a2 = rim_fma_k(672000., t, 6547968.);
-    a2 = rim_fma_k(a2, t, 2709504.);
-    a2 = rim_fma_k(a2, t, -28672.);
-    a1 = rim_fma_k(-645120., t, -2580480.);
-    a1 = rim_fma_k(a1, t, 0.);
-    a0 = rim_fma_k(1290240., t, 860160.);
-
-    double v = a7;
-    v = rim_fma(v, U, a6);
-    v = rim_fma(v, U, a5);
-    v = rim_fma(v, U, a4);
-    v = rim_fma(v, U, a3);
-    v = rim_fma(v, U, a2);
-    v = rim_fma(v, U, a1);
-    v = rim_fma(v, U, a0);
+    // each coefficient row is folded into the Horner value in U as soon as it is formed (one row live at a time)
+    double v, ak;
+    v = rim_fma_k(59968440., t, 4450158720.);
+    v = rim_fma_k(v, t, 38435160960.);
+    v = rim_fma_k(v, t, 86387857920.);
+    v = rim_fma_k(v, t, 60631119360.);
+    v = rim_fma_k(v, t, 12841758720.);
+    v = rim_fma_k(v, t, 625766400.);
+    v = rim_fma_k(v, t, 2580480.);
+    v = rim_fma_k(v, t, 0.);                          // a7
+    ak = rim_fma_k(-16907985., t, -954875250.);
+    ak = rim_fma_k(ak, t, -5897669400.);
+    ak = rim_fma_k(ak, t, -8653594320.);
+    ak = rim_fma_k(ak, t, -3405435264.);
+    ak = rim_fma_k(ak, t, -299351808.);
+    ak = rim_fma_k(ak, t, -2644992.);
+    ak = rim_fma_k(ak, t, 6144.);                     // a6
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(5537280., t, 228049920.);
+    ak = rim_fma_k(ak, t, 940423680.);
+    ak = rim_fma_k(ak, t, 800163840.);
+    ak = rim_fma_k(ak, t, 138700800.);
+    ak = rim_fma_k(ak, t, 2580480.);
+    ak = rim_fma_k(ak, t, 0.);                        // a5
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(-2163168., t, -61254720.);
+    ak = rim_fma_k(ak, t, -151828480.);
+    ak = rim_fma_k(ak, t, -60518400.);
+    ak = rim_fma_k(ak, t, -2519040.);
+    ak = rim_fma_k(ak, t, -8192.);                    // a4
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(-1048320., t, -18708480.);
+    ak = rim_fma_k(ak, t, -23224320.);
+    ak = rim_fma_k(ak, t, -2580480.);
+    ak = rim_fma_k(ak, t, 0.);                        // a3
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(672000., t, 6547968.);
+    ak = rim_fma_k(ak, t, 2709504.);
+    ak = rim_fma_k(ak, t, -28672.);                   // a2
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(-645120., t, -2580480.);
+    ak = rim_fma_k(ak, t, 0.);                        // a1
+    v = rim_fma(v, U, ak);
+    ak = rim_fma_k(1290240., t, 860160.);             // a0
+    v = rim_fma(v, U, ak);
     const double vsum1 = rim_div_by(U * v, 0.10321920e8, 1. / 0.10321920e8);
 
     const double factor = rim_div_moderate(1., o.np1 * rim_sqrt(Z));
