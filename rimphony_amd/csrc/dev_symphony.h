@@ -218,9 +218,10 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     const double cos_th = pt.cos_th, sin_th = pt.sin_th;
 
     const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-    const double cos_xi = (s * gamma - n) / (s * gamma * beta * cos_th);
+    // (numerators that can be exactly 0 give the IEEE signed zero through the bare sequence too)
+    const double cos_xi = rim_div_moderate(s * gamma - n, s * gamma * beta * cos_th);
     const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
-    const double m = (cos_th - beta * cos_xi) / sin_th;
+    const double m = rim_div_moderate(cos_th - beta * cos_xi, sin_th);
     const double big_n = beta * sin_xi;
 
     double gamma_sin_xi;
