@@ -237,10 +237,12 @@ __device__ __forceinline__ void qag_uniformize(QagState &q)
 __device__ __forceinline__ void qag_uniformize_live(QagState &q, double epsabs, double epsrel, int limit)
 {
     q.epsabs = epsabs; q.epsrel = epsrel; q.limit = limit;
-    q.area = uni(q.area); q.errsum = uni(q.errsum); q.tolerance = uni(q.tolerance);
+    q.area = uni(q.area); q.errsum = uni(q.errsum);
+    q.tolerance = 0.;                          // recomputed from area before every use
     q.iteration = uni(q.iteration); q.rt1 = uni(q.rt1); q.rt2 = uni(q.rt2);
-    q.error_type = uni(q.error_type); q.size = uni(q.size); q.imax = uni(q.imax);
-    q.a1 = uni(q.a1); q.b1 = uni(q.b1); q.a2 = uni(q.a2); q.b2 = uni(q.b2);
+    q.error_type = 0;                          // a running QAG has error_type == 0 (it ends the loop otherwise)
+    q.size = uni(q.size); q.imax = uni(q.imax);
+    q.a1 = uni(q.a1); q.b1 = uni(q.b1); q.a2 = q.b1; q.b2 = uni(q.b2);      // the children share their midpoint
     q.r_i = uni(q.r_i); q.e_i = uni(q.e_i);
     q.status = QAG_SUCCESS; q.result = 0.; q.abserr = 0.;
 }
@@ -547,10 +549,10 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
         if (lane == 0) {
             // only what is live across the integrand (qag_uniformize_live reads exactly these back)
             QagState &pq = park->q;
-            pq.area = q.area; pq.errsum = q.errsum; pq.tolerance = q.tolerance;
+            pq.area = q.area; pq.errsum = q.errsum;
             pq.iteration = q.iteration; pq.rt1 = q.rt1; pq.rt2 = q.rt2;
-            pq.error_type = q.error_type; pq.size = q.size; pq.imax = q.imax;
-            pq.a1 = q.a1; pq.b1 = q.b1; pq.a2 = q.a2; pq.b2 = q.b2; pq.r_i = q.r_i; pq.e_i = q.e_i;
+            pq.size = q.size; pq.imax = q.imax;
+            pq.a1 = q.a1; pq.b1 = q.b1; pq.b2 = q.b2; pq.r_i = q.r_i; pq.e_i = q.e_i;
             park->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
             park->ctr.steps += 1;
             if (park->hb) {
