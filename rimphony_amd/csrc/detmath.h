@@ -409,6 +409,17 @@ RIM_FN double rim_pow15(double x) { return x * rim_sqrt(x); }
 /* x^2.5 as x^2 * sqrt(x) (three roundings) */
 RIM_FN double rim_pow25(double x) { return (x * x) * rim_sqrt(x); }
 
+/* x^y from a double-double log of x that the caller already holds (lh + ll = rim_log_dd(x)): the last two steps
+ * of rim_pow_pos, for callers that raise one x to several powers. */
+RIM_FN double rim_pow_from_log(double lh, double ll, double y)
+{
+    const double ph = y * lh;
+    const double pl = rim_fma(y, lh, -ph) + y * ll;
+    if (ph > 800.0) return RIM_INF;
+    if (ph < -800.0) return 0.0;
+    return rim_exp_dd(ph, pl);
+}
+
 /* rim_pow(x, y) for a positive, finite x and a finite y: the same three steps (double-double log, product,
  * exp of the sum) without the dozen special-case tests in front of them, hence the same bits on that domain
  * (x = 1 and y = 0 still give exactly 1: log 1 = 0 and exp 0 = 1 are exact here).  tests/test_detmath.py. */

@@ -166,6 +166,22 @@ RIM_DEV HeyConsts hey_consts(const double *series_tab)
     return c;
 }
 
+// The four I_nu(x) of a quasi-resonant sample (nu = 2/3, -2/3, 1/3, -1/3): the same values as four bessel_i_g
+// calls, with the double-double log of x/2 that the four powers (x/2)^nu start from taken once.
+RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
+{
+    const double h = 0.5 * x;
+    const double hsq = h * h;
+    double ll;
+    const double lh = rim_log_dd(h, &ll);
+    const double gam[4] = { hc.g_p23, hc.g_m23, hc.g_p13, hc.g_m13 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int j = 0; j < 4; j++)
+        out[j] = rim_pow_from_log(lh, ll, hey_series_order(j)) / gam[j] * ascending_series_tab(hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
+}
+
 // Observer data of one Faraday coefficient (wave-uniform)
 struct HeyPoint {
     double s, cos_th, sin_th, sigma0, sigma0_sq;
@@ -218,11 +234,10 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
       RIM_PROF_COUNT(24, __builtin_popcountll(big)); }
 #endif
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
-        const double plus = bessel_i_g(0, hc.g_p23, hc.tab, g);
-        const double minus = bessel_i_g(1, hc.g_m23, hc.tab, g);
+        double iv[4];
+        bessel_i_g4(hc, g, iv);
+        const double plus = iv[0], minus = iv[1], plus1 = iv[2], minus1 = iv[3];
         y1 = RIM_FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
-        const double plus1 = bessel_i_g(2, hc.g_p13, hc.tab, g);
-        const double minus1 = bessel_i_g(3, hc.g_m13, hc.tab, g);
         y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
     } else {
         double js, ys, jm1, ym1;
@@ -269,10 +284,12 @@ RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
     double y;
     if (g < RIM_G_APPROXIMATION_CUTOFF) {
+        double iv[4];
+        bessel_i_g4(hc, g, iv);
         y = RIM_INVERSE_SQRT_3
             * g
-            * (bessel_i_g(1, hc.g_m23, hc.tab, g) - bessel_i_g(0, hc.g_p23, hc.tab, g))
-            * (bessel_i_g(3, hc.g_m13, hc.tab, g) + bessel_i_g(2, hc.g_p13, hc.tab, g));
+            * (iv[1] - iv[0])
+            * (iv[3] + iv[2]);
     } else {
         double js, ys, jm1, ym1;
         bessel_jy_set(c.sigma, c.x, false, &js, &ys, &jm1, &ym1);
