@@ -114,6 +114,10 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
         rim_sincos(RIM_PI * nu, &sn[w], &cs[w]);
     }
     // jobs: 0 J(sigma), 1 J(sigma-1), 2 J(-nu_y0), 3 J(-nu_y1), 4 J(nu_y0) if perturbed, 5 J(nu_y1) if perturbed
+    // (the six prefactors (x/2)^nu start from one double-double log of x/2)
+    const double h = 0.5 * x, hsq = h * h;
+    double ll;
+    const double lh = rim_log_dd(h, &ll);
     double r[6];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma nounroll
@@ -126,7 +130,7 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
         else if (k < 4) { nu = -nu_y[w]; need = w == 0 || want_ym1; }
         else { nu = nu_y[w]; need = (w == 0 || want_ym1) && nu_y[w] != sigma - (double) w; }
         double v = 0.;
-        if (need) v = bessel_jnu(nu, x);
+        if (need) v = rim_pow_from_log(lh, ll, nu) / gamma_real(nu + 1.) * ascending_series(nu, hsq, -1.);   // = bessel_jnu(nu, x)
         r[k] = v;
     }
     *js = r[0];
