@@ -1118,7 +1118,17 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
     // more waves than tasks on small batches: the surplus waves start as helpers right away
     const unsigned long long want_waves = ntasks > (1ull << 40) ? ntasks : ntasks * 64ull;
-    const unsigned grid = persistent_grid(c, want_waves, 4 * (int) P::WAVES);
+    // Every wave of the grid must be resident: an idle wave waits for the waves that still own a task, so a wave
+    // that cannot start until another one exits would be waited for forever.  Ask the runtime how many of these
+    // workgroups a CU really holds (registers, LDS) instead of trusting the launch bounds.
+    static int resident_per_cu = 0;
+    if (resident_per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coop_kernel<P>, 64, RIM_DYN_LDS) != hipSuccess || nb < 1)
+            nb = 4;       // conservative: one wave per SIMD
+        resident_per_cu = nb < 4 * (int) P::WAVES ? nb : 4 * (int) P::WAVES;
+    }
+    const unsigned grid = persistent_grid(c, want_waves, resident_per_cu);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
     if (c->board_slots < grid) {
