@@ -406,6 +406,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     unsigned seq = 0;                      // sequence number of this wave's published batches
     bool counted_idle = false;             // this wave is currently counted in flags[IDLE]
     int backoff = 1;
+    unsigned long long idle_since = 0;     // wall clock of the first empty poll since this wave last evaluated a request
     // diagnostics of the cooperative tail (queue words 8..13)
     unsigned n_polls = 0;
 #if defined(RIM_COOP_DIAG)
@@ -577,6 +578,16 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             COOP_DIAG(n_polls_total += 1;)
             if (h == 0) {
                 if (act == 0) break;       // every task is finished
+                // A wave that has seen nothing to do for 2 s leaves.  It holds no claim, so leaving is always safe,
+                // and it bounds every wait in this kernel: should part of the grid not be resident (the launch
+                // sizes it so that it is), the waves waiting for a slot get one instead of being waited for.
+                const unsigned long long now = wall_clock64();
+                if (idle_since == 0) idle_since = now;
+                else if (now - idle_since > 200000000ull) {
+                    if (counted_idle && lane == 0)
+                        __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
                 if (backoff < 16) backoff *= 2;
                 continue;
@@ -620,6 +631,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                         counted_idle = false;
                     }
                     backoff = 1;
+                    idle_since = 0;
                 }
                 n = uni(rim_frombits(bget(&src->req_n[k])));
                 lb = __builtin_amdgcn_readfirstlane(bget(&src->req_lobe[k]));
