@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // More idle waves than the remaining owners can feed (a batch has <= 62 requests) only
                     // add polling traffic, which slows the waves that compute: the surplus leaves.
-                    const unsigned keep = act * 96u + 128u;
+                    const unsigned keep = act * 64u + 32u;
                     if (counted_idle && act != 0 &&
                         __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > keep) {
                         const unsigned before = __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
