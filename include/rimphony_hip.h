@@ -200,6 +200,13 @@ double pkgw_bessel_dj(double n, double x);
 int rimphony_highfreq_batch_device(rimphony_ctx *ctx, int dist_kind, size_t n, const double *d_s, const double *d_theta,
                                    const double *const *d_params, double *d_out, void *stream);
 
+/* Diagnostic seam: diagnostic_symphony_n_integral (lib.rs:254-260 -> symphony.rs:298-307), the QAG over the
+ * harmonic number n in [n_lo[i], n_hi[i]] of the gamma-integral, for one parameter point.  A GSL error of the
+ * reference (its Err) is NaN here. */
+int rimphony_n_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params,
+                                     int coeff, int stokes, int negative_lobe, double s, double theta,
+                                     size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out, void *stream);
+
 /* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1

@@ -281,6 +281,23 @@ double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negati
     return r;
 }
 
+/* diagnostic_symphony_n_integral (lib.rs:254-260 -> symphony.rs:298-307): one QAG over n in [n_lo, n_hi] of the
+ * gamma-integral (limit 1000, eps_rel 1e-3).  Returns the GSL status; *value is only meaningful for 0. */
+int rimo_n_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta,
+                    double n_lo, double n_hi, double *value)
+{
+    sym_state st;
+    sym_init(&st, d, coeff, stokes, s, theta, NULL);
+    st.negative_lobe = negative_lobe;
+    rimo_workspace *n_ws = rimo_workspace_alloc(1000);
+    double abserr;
+    uint64_t nev = 0;
+    const int status = rimo_qag(gamma_integral_cb, &st, n_lo, n_hi, 0., 1e-3, 1000, n_ws, value, &abserr, &nev);
+    rimo_workspace_free(n_ws);
+    rimo_workspace_free(st.gamma_ws);
+    return status;
+}
+
 /* ---- lib.rs dispatch and scaling --------------------------------------- */
 
 double rimo_compute_dimensionless(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c)

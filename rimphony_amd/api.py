@@ -226,6 +226,18 @@ class Context:
         torch.cuda.synchronize(self._dev())
         return out.cpu().numpy()
 
+    def n_integral_batch(self, kind, params, coeff, stokes, negative_lobe, s, theta, n_lo, n_hi):
+        """diagnostic_symphony_n_integral over arrays of [n_lo, n_hi] ranges of one parameter point."""
+        dlo, dhi = self._as_dev(n_lo), self._as_dev(n_hi)
+        out = torch.empty_like(dlo)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_n_integral_batch_device(
+            self.handle, kind, par, int(coeff), int(stokes), int(negative_lobe), s, theta, dlo.numel(),
+            ctypes.c_void_p(dlo.data_ptr()), ctypes.c_void_p(dhi.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()),
+            "rimphony_n_integral_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def qag_selftest(self, family, p0, p1, a, b, epsabs, epsrel, limit):
         fam = torch.as_tensor(family, dtype=torch.int32).to(self._dev()).contiguous()
         d = [self._as_dev(v) for v in (p0, p1, a, b)]

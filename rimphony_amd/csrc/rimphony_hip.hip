@@ -880,6 +880,70 @@ __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const 
     }
 }
 
+// diagnostic_symphony_n_integral (lib.rs:254-260): one outer QAG over n in [n_lo, n_hi] of the gamma-integral,
+// run through the same post / evaluate / consume steps as a chunk of n_integration.
+template <int KIND>
+__global__ __launch_bounds__(64) void n_integral_kernel(PointArgs pa, const double *norm_ptr, size_t count,
+                                                        const double *n_lo, const double *n_hi, double *out, double *spill_base)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
+    __shared__ TaskState s_park;
+    const GKLane g = gk_lane_init(s_tab);
+    double *spill = spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
+    SymPoint pt;
+    pt.s = pa.s;
+    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
+    pt.coeff = pa.coeff;
+    pt.stokes = pa.stokes;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
+        TaskState T;
+        sym_begin(pt, T);
+        T.phase = PH_QAG_FIRST;
+        T.lobe = pa.negative_lobe;
+        T.qa = uni(n_lo[i]);
+        T.qb = uni(n_hi[i]);
+        T.ni_failed = 0;
+        qag_begin(T.oq, 0., 1e-3, 1000);
+        while (T.phase == PH_QAG_FIRST || T.phase == PH_QAG_BISECT) {
+            SymBatch B;
+            if (!sym_post(pt, g, outer, T, B)) break;
+            __syncthreads();
+            if (g.lane == 0) s_park = T;
+            int batch_status = 0;
+            double gval = 0.;
+            unsigned long long mask = wv_ballot(B.req_active);
+            while (mask) {
+                const int k = __builtin_ffsll((long long) mask) - 1;
+                mask &= mask - 1;
+                const double n = readlane_d(B.req_n, k);
+                const int lb = wv_readlane(B.req_lobe, k);
+                const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, batch_status);
+                if (g.lane == k) gval = val;
+            }
+            __syncthreads();
+            T = s_park;
+            task_uniformize(T);
+            sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
+        }
+        // sym_consume has run the chunk's epilogue: contrib holds the QAG value, ni_failed an Err
+        if (g.lane == 0) out[i] = (T.ni_failed || (T.status & ST_OUTER_FAIL)) ? RIM_NAN : T.contrib;
+    }
+}
+
+extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
+                                                int coeff, int stokes, int negative_lobe, double s, double theta,
+                                                size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out,
+                                                void *stream);
+
 __device__ inline double selftest_integrand(int family, double p0, double p1, double x)
 {
     switch (family) {
@@ -1527,6 +1591,33 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
+                                                int coeff, int stokes, int negative_lobe, double s, double theta,
+                                                size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out,
+                                                void *stream)
+{
+    if (!c || (count && (!d_n_lo || !d_n_hi || !d_out))) return RIMPHONY_EINVAL;
+    PointArgs pa;
+    int rc = fill_point_args(kind, params, coeff, stokes, negative_lobe, s, theta, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    rc = single_point_norm(c, kind, params, st);
+    if (rc) return rc;
+    const unsigned grid = persistent_grid(c, count, 16);
+    rc = ensure_spill(c, grid);
+    if (rc) return rc;
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(n_integral_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
+    case 1: hipLaunchKernelGGL(n_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
+    case 2: hipLaunchKernelGGL(n_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
+    default: hipLaunchKernelGGL(n_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;

@@ -65,6 +65,8 @@ def load(flavour="det"):
     L.rimo_deriv_central.restype = c_int
     L.rimo_deriv_central.argtypes = [FN, c_void_p, c_double, c_double, dp, dp]
     L.rimo_hyperg_2F1_at_1.restype = c_double; L.rimo_hyperg_2F1_at_1.argtypes = [c_double] * 3
+    L.rimo_n_integral.restype = c_int
+    L.rimo_n_integral.argtypes = [POINTER(Dist), c_int, c_int, c_int, c_double, c_double, c_double, c_double, dp]
     L.rimo_highfreq.restype = c_int; L.rimo_highfreq.argtypes = [c_int, dp, c_double, c_double, dp]
     L.rimo_bessel_k012.restype = None; L.rimo_bessel_k012.argtypes = [c_double, dp]
     L.rimo_build_flavour.restype = ctypes.c_char_p
@@ -133,3 +135,10 @@ def bessel_k012(L, x):
     k = (c_double * 3)()
     L.rimo_bessel_k012(float(x), k)
     return k[0], k[1], k[2]
+
+
+def n_integral(L, dist, coeff, stokes, negative_lobe, s, theta, n_lo, n_hi):
+    """diagnostic_symphony_n_integral: value, or NaN when the QAG reports an error (the Rust Err)."""
+    v = c_double()
+    rc = L.rimo_n_integral(ctypes.byref(dist), coeff, stokes, negative_lobe, s, theta, n_lo, n_hi, ctypes.byref(v))
+    return v.value if rc == 0 else float("nan")

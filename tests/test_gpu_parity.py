@@ -304,3 +304,20 @@ def test_api_misuse_is_an_error_code_not_a_crash(gpu_ctx):
     # the context is still usable afterwards
     got = gpu_ctx.compute_batch(0, [10.0], [0.8], [[2.5], [1.0], [1e12], [1e10]], 0x03)
     assert np.isfinite(got[0, :2]).all()
+
+
+def test_n_integral_diagnostic_bit_exact(gpu_ctx, oracle):
+    """diagnostic_symphony_n_integral (lib.rs:254-260): the outer QAG over n of the gamma-integral on [n_lo, n_hi]."""
+    rng = np.random.default_rng(31)
+    params = [2.8, 1.0, 1e12, 1e10]
+    s, th = 30., 0.9
+    d, st = oracle_bind.mkdist(oracle, 0, params)
+    assert st == 0
+    n_minus = s * math.sin(th)
+    lo = n_minus + 31. + rng.uniform(0., 50., 24)
+    hi = lo * rng.uniform(1.05, 3., 24)
+    for coeff, stokes, lobe in ((0, 0, 0), (1, 1, 0), (0, 2, 1)):
+        got = gpu_ctx.n_integral_batch(0, params, coeff, stokes, lobe, s, th, lo, hi)
+        ref = np.array([oracle_bind.n_integral(oracle, d, coeff, stokes, lobe, s, th, a, b) for a, b in zip(lo, hi)])
+        report_mismatch("n_integral", got, ref, lambda i: (coeff, stokes, lo[i], hi[i]))
+        assert np.isfinite(ref).sum() > 12
