@@ -78,13 +78,6 @@ RIM_DEV double ascending_series_tab(const double *row, double q, double sign)
     return sum;
 }
 
-// I_nu(x) for the j-th tabulated order, with Gamma(nu + 1) supplied
-RIM_DEV double bessel_i_g(int j, double gam, const double *tab, double x)
-{
-    const double h = 0.5 * x;
-    return rim_pow_pos(h, hey_series_order(j)) / gam * ascending_series_tab(tab + j * RIM_SERIES_ROW, h * h, 1.);
-}
-
 RIM_DEV double bessel_jnu(double nu, double x)
 {
     const double h = 0.5 * x;
