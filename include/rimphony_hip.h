@@ -207,6 +207,12 @@ int rimphony_n_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const dou
                                      int coeff, int stokes, int negative_lobe, double s, double theta,
                                      size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out, void *stream);
 
+/* Diagnostic seam: diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567), the
+ * contribution of all harmonics at fixed gamma (cgs-scaled like a coefficient), for one parameter point. */
+int rimphony_gamma_contribution_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params, int coeff, int stokes,
+                                             double s, double theta, size_t count, const double *d_gamma, double *d_out,
+                                             void *stream);
+
 /* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1

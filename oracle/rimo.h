@@ -126,6 +126,7 @@ double rimo_hey_element(const rimo_dist *d, int stokes, double s, double theta, 
 
 /* diagnostics (lib.rs:254-298) */
 double rimo_gamma_integrand(const rimo_dist *d, int coeff, int stokes, double s, double theta, double n, double gamma);
+double rimo_gamma_contribution(const rimo_dist *d, int coeff, int stokes, double s, double theta, double gamma);
 int rimo_n_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta,
                     double n_lo, double n_hi, double *value);
 double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta, double n);

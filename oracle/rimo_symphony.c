@@ -298,6 +298,45 @@ int rimo_n_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe
     return status;
 }
 
+/* diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567): the contribution of all
+ * harmonics n at fixed gamma -- the Symphony double integral with the order of integration reversed. */
+typedef struct { sym_state *st; double gamma; } contrib_ctx;
+static double contrib_cb(double n, void *ctx)
+{
+    contrib_ctx *c = (contrib_ctx *) ctx;
+    return gamma_integrand(c->st, c->gamma, n);
+}
+
+double rimo_gamma_contribution(const rimo_dist *d, int coeff, int stokes, double s, double theta, double gamma)
+{
+    const int64_t FULLY_DISCRETE_THRESHOLD = 1000, N_DISCRETE = 30;
+    sym_state st;
+    sym_init(&st, d, coeff, stokes, s, theta, NULL);
+    const double delta = m_fabs(st.cos_observer_angle) * m_sqrt(gamma * gamma - 1.);
+    const int64_t n_minus = sat_i64(s * (gamma - delta) + 1.);
+    const int64_t n_plus = sat_i64(s * (gamma + delta));
+    double ans = 0.;
+    if (n_plus - n_minus < FULLY_DISCRETE_THRESHOLD) {
+        for (int64_t n = n_minus; n < n_plus + 1; n++) ans += gamma_integrand(&st, gamma, (double) n);
+    } else {
+        for (int64_t n = n_minus; n < n_minus + N_DISCRETE + 1; n++) ans += gamma_integrand(&st, gamma, (double) n);
+        contrib_ctx c = { &st, gamma };
+        rimo_workspace *ws = rimo_workspace_alloc(5000);
+        double contrib, abserr;
+        uint64_t nev = 0;
+        const int status = rimo_qag(contrib_cb, &c, (double) (n_minus + N_DISCRETE + 1), (double) n_plus, 0., 1e-3, 5000, ws,
+                                    &contrib, &abserr, &nev);
+        rimo_workspace_free(ws);
+        ans += status ? RIM_NAN : contrib;
+    }
+    rimo_workspace_free(st.gamma_ws);
+    if (!rim_isfinite(ans)) return RIM_NAN;
+    const double tpe = TWO_PI * ELECTRON_CHARGE;
+    const double acos_th = m_fabs(st.cos_observer_angle);
+    if (coeff == RIMO_EMISSION) return ans * ((tpe * tpe) / (SPEED_LIGHT * acos_th));
+    return ans * (-1. * (tpe * tpe) / (2. * MASS_ELECTRON * SPEED_LIGHT * acos_th));
+}
+
 /* ---- lib.rs dispatch and scaling --------------------------------------- */
 
 double rimo_compute_dimensionless(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c)

@@ -238,6 +238,18 @@ class Context:
         torch.cuda.synchronize(self._dev())
         return out.cpu().numpy()
 
+    def gamma_contribution_batch(self, kind, params, coeff, stokes, s, theta, gamma):
+        """diagnostic_symphony_gamma_contribution over an array of gammas of one parameter point."""
+        dg = self._as_dev(gamma)
+        out = torch.empty_like(dg)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_gamma_contribution_batch_device(
+            self.handle, kind, par, int(coeff), int(stokes), s, theta, dg.numel(),
+            ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()),
+            "rimphony_gamma_contribution_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def qag_selftest(self, family, p0, p1, a, b, epsabs, epsrel, limit):
         fam = torch.as_tensor(family, dtype=torch.int32).to(self._dev()).contiguous()
         d = [self._as_dev(v) for v in (p0, p1, a, b)]

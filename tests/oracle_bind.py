@@ -65,6 +65,8 @@ def load(flavour="det"):
     L.rimo_deriv_central.restype = c_int
     L.rimo_deriv_central.argtypes = [FN, c_void_p, c_double, c_double, dp, dp]
     L.rimo_hyperg_2F1_at_1.restype = c_double; L.rimo_hyperg_2F1_at_1.argtypes = [c_double] * 3
+    L.rimo_gamma_contribution.restype = c_double
+    L.rimo_gamma_contribution.argtypes = [POINTER(Dist), c_int, c_int, c_double, c_double, c_double]
     L.rimo_n_integral.restype = c_int
     L.rimo_n_integral.argtypes = [POINTER(Dist), c_int, c_int, c_int, c_double, c_double, c_double, c_double, dp]
     L.rimo_highfreq.restype = c_int; L.rimo_highfreq.argtypes = [c_int, dp, c_double, c_double, dp]

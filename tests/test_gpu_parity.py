@@ -4,6 +4,7 @@ elementary functions and the GK31 reduction tree with the kernels; DESIGN.md
 "Rounding contract").  north_star's stated tolerance is 1e-6 relative; where a
 test cannot be bit-exact it says so and uses that tolerance.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -321,3 +322,19 @@ def test_n_integral_diagnostic_bit_exact(gpu_ctx, oracle):
         ref = np.array([oracle_bind.n_integral(oracle, d, coeff, stokes, lobe, s, th, a, b) for a, b in zip(lo, hi)])
         report_mismatch("n_integral", got, ref, lambda i: (coeff, stokes, lo[i], hi[i]))
         assert np.isfinite(ref).sum() > 12
+
+
+def test_gamma_contribution_diagnostic_bit_exact(gpu_ctx, oracle):
+    """diagnostic_symphony_gamma_contribution (lib.rs:288-296): fully discrete sums (few harmonics) and the
+    31-discrete + QAG-over-n branch (more than 1000 harmonics)."""
+    rng = np.random.default_rng(32)
+    params = [2.8, 1.0, 1e12, 1e10]
+    d, st = oracle_bind.mkdist(oracle, 0, params)
+    assert st == 0
+    for s, th, glo, ghi in ((8., 0.9, 1.5, 30.), (400., 0.6, 3., 40.)):
+        gam = np.exp(rng.uniform(math.log(glo), math.log(ghi), 12))
+        for coeff, stokes in ((0, 0), (1, 1)):
+            got = gpu_ctx.gamma_contribution_batch(0, params, coeff, stokes, s, th, gam)
+            ref = np.array([oracle.rimo_gamma_contribution(ctypes.byref(d), coeff, stokes, s, th, float(x)) for x in gam])
+            report_mismatch("gamma_contribution", got, ref, lambda i: (s, coeff, stokes, gam[i]))
+            assert np.isfinite(ref).sum() >= 6
