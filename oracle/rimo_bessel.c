@@ -13,10 +13,11 @@
  * that branch; the 0.6666666 slope literal; n >= 1e15 -> NaN in the
  * derivative; x > 1e55 -> NaN in the Debye expansion; non-integer n < 30 -> NaN.
  *
- * Not restated: BesselJ_Meissel_Second (bessel.c:57-88, x > n, long double
- * acosl/cosl).  The hot path never reaches it (hard part
- * 2: z/n < 1 always); outside the Debye band on the x > n side this oracle and
- * the kernels return NaN.
+ * BesselJ_Meissel_Second (bessel.c:57-88, x > n) evaluates acos and the cosine of
+ * its phase in long double; the libm build does the same, the deterministic build
+ * (and the HIP library) use fp64 functions of detmath.h -- a phase error of about
+ * n * 1e-15.  The hot path never reaches that expansion (hard
+ * part 2: z/n < 1 always); it completes the pkgw_bessel_j seam.
  *
  * Horner steps are fused multiply-adds in the default build (one rounding
  * instead of two; the reference's C is unfused) -- the HIP kernels use the
@@ -272,6 +273,67 @@ double rimo_bessel_jn_int(int n, double x)
 static const double MINUS_ETA_A_INTERCEPT = 0.174857;
 static const double MINUS_ETA_B_INTERCEPT = 0.295966;
 static const double PLUS_ETA_A_INTERCEPT = 0.151550;
+static const double PLUS_ETA_B_INTERCEPT = 0.438914;
+
+/* Meissel's "second" expansion (bessel.c:57-88), x > n.  Not on the hot path; completes pkgw_bessel_j.
+ * The reference computes acos and the cosine of the phase in long double (kept in the libm build);
+ * the deterministic build uses the fp64 functions of detmath.h, as the HIP library does. */
+static double meissel_second(const double n, const double x)
+{
+    const double z = x / n;
+    const double eps = (x - n) / n;
+    const double Z = m_sqrt(eps * (1 + z));
+    const double U = 1. / (n * Z * Z * Z);
+    const double t1 = z * z;
+    const double t2 = U * U;
+
+    double p3 = m_fma(71391., t1, 5297808.);
+    p3 = m_fma(p3, t1, 45756144.);
+    p3 = m_fma(p3, t1, 102842688.);
+    p3 = m_fma(p3, t1, 72179904.);
+    p3 = m_fma(p3, t1, 15287808.);
+    p3 = m_fma(p3, t1, 744960.);
+    p3 = m_fma(p3, t1, 3072.);
+    double p2 = m_fma(-6592., t1, -271488.);
+    p2 = m_fma(p2, t1, -1119552.);
+    p2 = m_fma(p2, t1, -952576.);
+    p2 = m_fma(p2, t1, -165120.);
+    p2 = m_fma(p2, t1, -3072.);
+    double p1 = m_fma(1248., t1, 22272.);
+    p1 = m_fma(p1, t1, 27648.);
+    p1 = m_fma(p1, t1, 3072.);
+    const double p0 = m_fma(-768., t1, -3072.);
+    double pe = m_fma(p3, t2, p2);
+    pe = m_fma(pe, t2, p1);
+    pe = m_fma(pe, t2, p0);
+    const double exp_val = (t1 * t2 * pe) / 0.12288e5;
+
+    const double Qt = n * (Z - m_acos01(n / x));
+
+    double q3 = m_fma(16907985., t1, 954875250.);
+    q3 = m_fma(q3, t1, 5897669400.);
+    q3 = m_fma(q3, t1, 8653594320.);
+    q3 = m_fma(q3, t1, 3405435264.);
+    q3 = m_fma(q3, t1, 299351808.);
+    q3 = m_fma(q3, t1, 2644992.);
+    q3 = m_fma(q3, t1, -6144.);
+    double q2 = m_fma(2163168., t1, 61254720.);
+    q2 = m_fma(q2, t1, 151828480.);
+    q2 = m_fma(q2, t1, 60518400.);
+    q2 = m_fma(q2, t1, 2519040.);
+    q2 = m_fma(q2, t1, 8192.);
+    double q1 = m_fma(-672000., t1, -6547968.);
+    q1 = m_fma(q1, t1, -2709504.);
+    q1 = m_fma(q1, t1, 28672.);
+    const double q0 = m_fma(1290240., t1, 860160.);
+    double qs = m_fma(q3, t2, q2);
+    qs = m_fma(qs, t2, q1);
+    qs = m_fma(qs, t2, q0);
+    const double Qsum = -(U * qs) / 0.10321920e8;
+
+    const double factor = m_sqrt(2 / (RIM_PI * n * Z)) * m_cos_phase(Qsum + Qt - 0.78539816339744830962);
+    return exp_factor(factor, exp_val);
+}
 
 double rimo_bessel_j(const double n, const double x)
 {
@@ -310,10 +372,17 @@ double rimo_bessel_j(const double n, const double x)
     } else {
         const double eta = m_log10_region((x - n) / x);
         const double eta_thresh_lo = -0.6666666 * logn + PLUS_ETA_A_INTERCEPT;
+        const double eta_thresh_hi = -0.6666666 * logn + PLUS_ETA_B_INTERCEPT;
         if (eta < eta_thresh_lo)
             return debye_eps_exp(n, x);
-        /* Meissel "second" region: not restated (never reached by the hot path) */
-        return RIM_NAN;
+        if (eta > eta_thresh_hi)
+            return meissel_second(n, x);
+        {
+            const double debye = debye_eps_exp(n, x);
+            const double meissel2 = meissel_second(n, x);
+            const double pos = (eta - eta_thresh_lo) / (PLUS_ETA_B_INTERCEPT - PLUS_ETA_A_INTERCEPT);
+            return debye * (1 - pos) + meissel2 * pos;
+        }
     }
 }
 

@@ -13,6 +13,9 @@
 #define m_log(x) log(x)
 #define m_log10(x) log10(x)
 #define m_log10_region(x) log10(x)
+/* bessel.c:73,84 evaluate these two in long double */
+#define m_acos01(t) ((double) acosl((long double) (t)))
+#define m_cos_phase(x) ((double) cosl((long double) (x)))
 #define m_pow(x, y) pow(x, y)
 #define m_pow15(x) pow(x, 1.5)
 #define m_pow25(x) pow(x, 2.5)
@@ -24,6 +27,8 @@ static inline void m_sincos(double x, double *s, double *c) { *s = sin(x); *c = 
 #define m_log(x) rim_log(x)
 #define m_log10(x) rim_log10(x)
 #define m_log10_region(x) rim_log10_region(x)
+#define m_acos01(t) rim_acos01(t)
+static inline double m_cos_phase(double x) { double s, c; rim_sincos(x, &s, &c); return c; }
 #define m_pow(x, y) rim_pow(x, y)
 #define m_pow15(x) rim_pow15(x)
 #define m_pow25(x) rim_pow25(x)

@@ -447,6 +447,40 @@ RIM_FN double rim_pow_normal(double x, double y)
     return rim_exp_dd_core(ph, pl);
 }
 
+/* ---- atan, acos (only the Meissel "second" expansion of the Bessel seam needs them) -------------- */
+
+/* atan(u) for u >= 0: reflection for u > 1, three half-angle steps atan u = 2 atan(u / (1 + sqrt(1 + u^2)))
+ * down to u < 0.1, then the alternating series to u^21.  A few ulp. */
+RIM_FN double rim_atan_pos(double u)
+{
+    if (rim_isnan(u)) return u;
+    int reflect = 0;
+    if (u > 1.0) { u = 1.0 / u; reflect = 1; }       /* also maps +inf to 0 */
+    u = u / (1.0 + rim_sqrt(rim_fma(u, u, 1.0)));
+    u = u / (1.0 + rim_sqrt(rim_fma(u, u, 1.0)));
+    u = u / (1.0 + rim_sqrt(rim_fma(u, u, 1.0)));
+    const double z = u * u;
+    double q = -1.0 / 23.0;
+    q = rim_fma_k(q, z, 1.0 / 21.0);
+    q = rim_fma_k(q, z, -1.0 / 19.0);
+    q = rim_fma_k(q, z, 1.0 / 17.0);
+    q = rim_fma_k(q, z, -1.0 / 15.0);
+    q = rim_fma_k(q, z, 1.0 / 13.0);
+    q = rim_fma_k(q, z, -1.0 / 11.0);
+    q = rim_fma_k(q, z, 1.0 / 9.0);
+    q = rim_fma_k(q, z, -1.0 / 7.0);
+    q = rim_fma_k(q, z, 1.0 / 5.0);
+    q = rim_fma_k(q, z, -1.0 / 3.0);
+    const double a = 8.0 * rim_fma(u * z, q, u);
+    return reflect ? 1.5707963267948966 - a + 6.123233995736766e-17 : a;
+}
+
+/* acos(t) for 0 <= t <= 1 as 2 atan(sqrt((1 - t) / (1 + t))): no cancellation as t -> 1 */
+RIM_FN double rim_acos01(double t)
+{
+    return 2.0 * rim_atan_pos(rim_sqrt((1.0 - t) / (1.0 + t)));
+}
+
 /* ---- lgamma (positive arguments only) --------------------------------- */
 
 /* Stirling series for x >= 16 (error of the truncated series < 1e-19 rel). */

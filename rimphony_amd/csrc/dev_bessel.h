@@ -490,6 +490,70 @@ RIM_DEV void jn_int_pair(int n, double x, double *jn, double *jnp1)
     *jnp1 = tiny1 ? s1 : w1 / sum;
 }
 
+// Meissel's "second" expansion, x > n (bessel.c:57-88, Chishtie et al. 2005).  The integrator never gets here
+// (z/n < 1 on the whole path); it completes the Bessel seam for arbitrary arguments.  The reference evaluates
+// the phase n (Z - acos(n/x)) and its cosine in `long double`; here they are fp64 (rim_acos01, rim_sincos), so
+// the phase carries an absolute error of about n * 1e-15 -- the one place where this library and the reference
+// differ by more than rounding (oracle/rimo_bessel.c keeps acosl/cosl in its libm build).
+RIM_DEV double meissel_second(double n, double x)
+{
+    const double z = x / n;
+    const double eps = (x - n) / n;
+    const double Z = rim_sqrt(eps * (1 + z));
+    const double U = 1. / (n * Z * Z * Z);
+    const double t1 = z * z;
+    const double t2 = U * U;
+
+    double p3 = rim_fma_k(71391., t1, 5297808.);
+    p3 = rim_fma_k(p3, t1, 45756144.);
+    p3 = rim_fma_k(p3, t1, 102842688.);
+    p3 = rim_fma_k(p3, t1, 72179904.);
+    p3 = rim_fma_k(p3, t1, 15287808.);
+    p3 = rim_fma_k(p3, t1, 744960.);
+    p3 = rim_fma_k(p3, t1, 3072.);
+    double p2 = rim_fma_k(-6592., t1, -271488.);
+    p2 = rim_fma_k(p2, t1, -1119552.);
+    p2 = rim_fma_k(p2, t1, -952576.);
+    p2 = rim_fma_k(p2, t1, -165120.);
+    p2 = rim_fma_k(p2, t1, -3072.);
+    double p1 = rim_fma_k(1248., t1, 22272.);
+    p1 = rim_fma_k(p1, t1, 27648.);
+    p1 = rim_fma_k(p1, t1, 3072.);
+    const double p0 = rim_fma_k(-768., t1, -3072.);
+    double pe = rim_fma(p3, t2, p2);
+    pe = rim_fma(pe, t2, p1);
+    pe = rim_fma(pe, t2, p0);
+    const double exp_val = (t1 * t2 * pe) / 0.12288e5;
+
+    const double Qt = n * (Z - rim_acos01(n / x));
+
+    double q3 = rim_fma_k(16907985., t1, 954875250.);
+    q3 = rim_fma_k(q3, t1, 5897669400.);
+    q3 = rim_fma_k(q3, t1, 8653594320.);
+    q3 = rim_fma_k(q3, t1, 3405435264.);
+    q3 = rim_fma_k(q3, t1, 299351808.);
+    q3 = rim_fma_k(q3, t1, 2644992.);
+    q3 = rim_fma_k(q3, t1, -6144.);
+    double q2 = rim_fma_k(2163168., t1, 61254720.);
+    q2 = rim_fma_k(q2, t1, 151828480.);
+    q2 = rim_fma_k(q2, t1, 60518400.);
+    q2 = rim_fma_k(q2, t1, 2519040.);
+    q2 = rim_fma_k(q2, t1, 8192.);
+    double q1 = rim_fma_k(-672000., t1, -6547968.);
+    q1 = rim_fma_k(q1, t1, -2709504.);
+    q1 = rim_fma_k(q1, t1, 28672.);
+    const double q0 = rim_fma_k(1290240., t1, 860160.);
+    double qs = rim_fma(q3, t2, q2);
+    qs = rim_fma(qs, t2, q1);
+    qs = rim_fma(qs, t2, q0);
+    const double Qsum = -(U * qs) / 0.10321920e8;
+
+    double sn, cs;
+    rim_sincos(Qsum + Qt - 0.78539816339744830962, &sn, &cs);
+    const double factor = rim_sqrt(2 / (RIM_PI * n * Z)) * cs;
+    return exp_factor(factor, exp_val);
+}
+
 // Full pkgw_bessel_j / pkgw_bessel_dj for arbitrary (n, x): the scalar seam
 // (leung-bessel/src/lib.rs:36-42), used by the batch Bessel entry point.
 RIM_DEV double bessel_j(double n, double x)
@@ -504,6 +568,17 @@ RIM_DEV double bessel_j(double n, double x)
     }
     if (x == n) return debye_eps(n, x);
     const LeungOrder o = leung_order(n);
+    if (x > n) {
+        // bessel.c:358-375: Debye, Meissel-2, or their linear blend (PLUS_ETA_B_INTERCEPT = 0.438914)
+        const double eta = rim_log10_region((x - n) / x);
+        const double thr_hi = -0.6666666 * rim_log10(n) + 0.438914;
+        if (eta < o.thr_plus_lo) return debye_eps(n, x);
+        if (eta > thr_hi) return meissel_second(n, x);
+        const double debye = debye_eps(n, x);
+        const double meissel2 = meissel_second(n, x);
+        const double pos = (eta - o.thr_plus_lo) / (0.438914 - 0.151550);
+        return debye * (1 - pos) + meissel2 * pos;
+    }
     return leung_j(o, x);
 }
 

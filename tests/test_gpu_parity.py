@@ -49,6 +49,7 @@ def test_bessel_bit_exact(gpu_ctx, oracle):
     eta = rng.uniform(-12, 0, N)
     x = n * (1 - 10.0 ** eta)
     x = np.where(rng.random(N) < 0.05, n * (1 + 10.0 ** rng.uniform(-12, -3, N)), x)
+    x = np.where(rng.random(N) < 0.08, n * (1 + 10.0 ** rng.uniform(-4, 1, N)), x)      # x > n up to 11 n: Meissel "second"
     x = np.where(rng.random(N) < 0.02, n, x)
     x = np.where(rng.random(N) < 0.02, 0.0, x)
     j, dj = gpu_ctx.bessel_batch(n, x)

@@ -88,6 +88,8 @@ def test_device_bessel_host_build_bit_exact(devh, oracle):
         if rng.random() < 0.5 and n >= 1:
             n = float(math.floor(n))
         x = n * (1 - 10 ** rng.uniform(-12, 0)) if rng.random() < 0.9 else n * (1 + 10 ** rng.uniform(-12, -3))
+        if rng.random() < 0.08:
+            x = n * (1 + 10 ** rng.uniform(-4, 1))     # x > n: Debye / blend / Meissel "second" (bessel.c:358-375)
         if rng.random() < 0.02:
             x = n
         assert _same(oracle.rimo_bessel_j(n, x), devh.devh_bessel_j(n, x)), (n, x)

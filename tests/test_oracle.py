@@ -93,6 +93,26 @@ def test_bessel_smoke_and_bias(oracle):
             assert abs(oracle.rimo_bessel_j(n, x) / ref - n / (n + 1)) < 2e-4 * (30 / n) + 1e-9
 
 
+def test_bessel_x_above_n(oracle, oracle_libm):
+    """pkgw_bessel_j for x > n (bessel.c:358-375).  Against scipy's J_n, in units of the oscillation amplitude:
+    the Debye band to 1e-5, Meissel "second" to 1e-4, the blend zone between them only to a few percent -- that
+    is Leung's approximation itself (bessel.c:306-310 notes the overlap problem), not this restatement: the
+    deterministic build and the long-double/libm build of the oracle agree everywhere to the n * 1e-14 phase
+    error that evaluating acos and cos in fp64 introduces."""
+    rng = np.random.default_rng(17)
+    worst = 0.
+    for _ in range(4000):
+        n = float(np.exp(rng.uniform(math.log(30.), math.log(3e4))))
+        x = n * (1 + 10 ** rng.uniform(-3, 1))
+        amp = math.sqrt(2 / (math.pi * math.sqrt(x * x - n * n)))
+        eta, logn = math.log10((x - n) / x), math.log10(n)
+        tol = 1e-5 if eta < -0.6666666 * logn + 0.151550 else (1e-4 if eta > -0.6666666 * logn + 0.438914 else 5e-2)
+        got, ref = oracle.rimo_bessel_j(n, x), sp.jv(n, x)
+        assert abs(got - ref) <= tol * amp, (n, x, got, ref)
+        worst = max(worst, abs(got - oracle_libm.rimo_bessel_j(n, x)) / amp / n)
+    assert worst < 1e-14, worst
+
+
 def _qagiu_like(L, f, lo=1.0, hi=1e13):
     # the reference uses QAGIU on [1, inf); a log-substituted QAG on [1, hi] is ample for 1e-3
     st, r, e, sz, nev = oracle_bind.qag(L, lambda t: f(math.exp(t)) * math.exp(t), math.log(lo), math.log(hi), 0., 1e-6, 1000)
