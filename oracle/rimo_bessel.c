@@ -234,11 +234,45 @@ static int miller_start(double x)
     return N + (N & 1);      /* even */
 }
 
+/* J_n(x) for integer 0 <= n < 30 and x > 5e4, beyond the reach of the backward recurrence above: Hankel's */
+/* asymptotic expansion (x >> n^2 here, the terms fall off like (n^2 / 2x)^k).  GSL's gsl_sf_bessel_Jn covers */
+/* these arguments in the reference (bessel.c:327-333); the integrator never needs them (x < n + 1 <= 30). */
+static double jn_hankel(int n, double x)
+{
+    const double mu = 4. * (double) n * (double) n;
+    const double inv8x = 1. / (8. * x);
+    double term = 1., p = 1., q = 0.;
+    for (int k = 1; k <= 40; k++) {
+        const double odd = (double) (2 * k - 1);
+        const double next = term * ((mu - odd * odd) * inv8x / (double) k);
+        if (m_fabs(next) >= m_fabs(term) && k > 1) break;      /* the asymptotic series has started to diverge */
+        term = next;
+        /* terms alternate between Q (k odd) and P (k even), with signs + - - + + - - + ... */
+        if (k & 1) q = q + (((k >> 1) & 1) ? -term : term);
+        else p = p + (((k >> 1) & 1) ? -term : term);
+        if (m_fabs(term) < 1e-18) break;
+    }
+    /* chi = x - (2n + 1) pi / 4: rotate (cos x, sin x) by an exact multiple of pi/4 */
+    double sx, cx;
+    m_sincos(x, &sx, &cx);
+    const double r = 0.70710678118654752440;
+    double cphi, sphi;
+    switch ((2 * n + 1) & 7) {
+    case 1: cphi = r; sphi = r; break;
+    case 3: cphi = -r; sphi = r; break;
+    case 5: cphi = -r; sphi = -r; break;
+    default: cphi = r; sphi = -r; break;
+    }
+    const double cchi = cx * cphi + sx * sphi;
+    const double schi = sx * cphi - cx * sphi;
+    return m_sqrt(2. / (RIM_PI * x)) * (p * cchi - q * schi);
+}
+
 double rimo_bessel_jn_int(int n, double x)
 {
     if (n < 0 || !(x >= 0)) return RIM_NAN;
     if (x == 0.) return n == 0 ? 1. : 0.;
-    if (x > 5.0e4) return RIM_NAN;     /* outside the supported range (hot path has x < n + 1 <= 30) */
+    if (x > 5.0e4) return jn_hankel(n, x);     /* beyond the backward recurrence (hot path has x < n + 1 <= 30) */
 
     /* leading term of the power series suffices when (x/2)^2/(n+1) < 2^-55 */
     if (x * x < 1.0e-16 * (n + 1)) {

@@ -490,6 +490,40 @@ RIM_DEV void jn_int_pair(int n, double x, double *jn, double *jnp1)
     *jnp1 = tiny1 ? s1 : w1 / sum;
 }
 
+// J_n(x) for integer 0 <= n < 30 and x > 5e4, beyond the reach of the backward recurrence above: Hankel's
+// asymptotic expansion (x >> n^2 here, the terms fall off like (n^2 / 2x)^k).  GSL's gsl_sf_bessel_Jn covers
+// these arguments in the reference (bessel.c:327-333); the integrator never needs them (x < n + 1 <= 30).
+RIM_DEV double jn_hankel(int n, double x)
+{
+    const double mu = 4. * (double) n * (double) n;
+    const double inv8x = 1. / (8. * x);
+    double term = 1., p = 1., q = 0.;
+    for (int k = 1; k <= 40; k++) {
+        const double odd = (double) (2 * k - 1);
+        const double next = term * ((mu - odd * odd) * inv8x / (double) k);
+        if (rim_fabs(next) >= rim_fabs(term) && k > 1) break;      // the asymptotic series has started to diverge
+        term = next;
+        // terms alternate between Q (k odd) and P (k even), with signs + - - + + - - + ...
+        if (k & 1) q = q + (((k >> 1) & 1) ? -term : term);
+        else p = p + (((k >> 1) & 1) ? -term : term);
+        if (rim_fabs(term) < 1e-18) break;
+    }
+    // chi = x - (2n + 1) pi / 4: rotate (cos x, sin x) by an exact multiple of pi/4
+    double sx, cx;
+    rim_sincos(x, &sx, &cx);
+    const double r = 0.70710678118654752440;
+    double cphi, sphi;
+    switch ((2 * n + 1) & 7) {
+    case 1: cphi = r; sphi = r; break;
+    case 3: cphi = -r; sphi = r; break;
+    case 5: cphi = -r; sphi = -r; break;
+    default: cphi = r; sphi = -r; break;
+    }
+    const double cchi = cx * cphi + sx * sphi;
+    const double schi = sx * cphi - cx * sphi;
+    return rim_sqrt(2. / (RIM_PI * x)) * (p * cchi - q * schi);
+}
+
 // Meissel's "second" expansion, x > n (bessel.c:57-88, Chishtie et al. 2005).  The integrator never gets here
 // (z/n < 1 on the whole path); it completes the Bessel seam for arbitrary arguments.  The reference evaluates
 // the phase n (Z - acos(n/x)) and its cosine in `long double`; here they are fp64 (rim_acos01, rim_sincos), so
@@ -562,6 +596,7 @@ RIM_DEV double bessel_j(double n, double x)
     if (n < 30.) {
         const int n_int = (int) n;
         if (n_int != n) return RIM_NAN;
+        if (x > 5.0e4) return jn_hankel(n_int, x);
         double a, b;
         jn_int_pair(n_int, x, &a, &b);
         return a;

@@ -113,6 +113,17 @@ def test_bessel_x_above_n(oracle, oracle_libm):
     assert worst < 1e-14, worst
 
 
+def test_integer_orders_at_large_x(oracle):
+    """n < 30 goes to gsl_sf_bessel_Jn in the reference (bessel.c:327-333) for any x; beyond the backward
+    recurrence (x > 5e4) the restatement switches to Hankel's asymptotic expansion."""
+    rng = np.random.default_rng(19)
+    for _ in range(2000):
+        n = int(rng.integers(0, 30))
+        x = float(np.exp(rng.uniform(math.log(2e4), math.log(1e9))))
+        amp = math.sqrt(2 / (math.pi * x))
+        assert abs(oracle.rimo_bessel_j(float(n), x) - sp.jv(n, x)) <= 1e-9 * amp, (n, x)
+
+
 def _qagiu_like(L, f, lo=1.0, hi=1e13):
     # the reference uses QAGIU on [1, inf); a log-substituted QAG on [1, hi] is ample for 1e-3
     st, r, e, sz, nev = oracle_bind.qag(L, lambda t: f(math.exp(t)) * math.exp(t), math.log(lo), math.log(hi), 0., 1e-6, 1000)
