@@ -199,6 +199,9 @@ double pkgw_bessel_dj(double n, double x);
  * check is made that the parameters lie where the approximation is good. */
 int rimphony_highfreq_batch_device(rimphony_ctx *ctx, int dist_kind, size_t n, const double *d_s, const double *d_theta,
                                    const double *const *d_params, double *d_out, void *stream);
+/* The same with host buffers (synchronous). */
+int rimphony_highfreq_batch(rimphony_ctx *ctx, int dist_kind, size_t n, const double *s, const double *theta,
+                            const double *const *params, double *out);
 
 /* Diagnostic seam: diagnostic_symphony_n_integral (lib.rs:254-260 -> symphony.rs:298-307), the QAG over the
  * harmonic number n in [n_lo[i], n_hi[i]] of the gamma-integral, for one parameter point.  A GSL error of the

@@ -1516,6 +1516,42 @@ extern "C" int rimphony_batch_compute(rimphony_ctx *c, int kind, size_t n,
     return RIMPHONY_OK;
 }
 
+extern "C" int rimphony_highfreq_batch_device(rimphony_ctx *c, int kind, size_t n, const double *d_s, const double *d_theta,
+                                              const double *const *d_params, double *d_out, void *stream);
+
+// host-buffer form of rimphony_highfreq_batch_device (out: [n][2] = rho_Q, rho_V)
+extern "C" int rimphony_highfreq_batch(rimphony_ctx *c, int kind, size_t n, const double *s, const double *theta,
+                                       const double *const *params, double *out)
+{
+    if (!c || !params) return RIMPHONY_EINVAL;
+    if (kind != RIMPHONY_POWER_LAW && kind != RIMPHONY_THERMAL_JUETTNER) return RIMPHONY_EINVAL;
+    if (n == 0) return RIMPHONY_OK;
+    if (!s || !theta || !out) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const int np = kind == RIMPHONY_POWER_LAW ? 2 : 1;       // only p and gamma_min (or T) enter the closed forms
+    for (int k = 0; k < np; k++) if (!params[k]) return RIMPHONY_EINVAL;
+    const size_t need_in = n * (size_t) (2 + np + 2);
+    if (c->in_cap < need_in) {
+        if (c->d_in) (void) hipFree(c->d_in);
+        c->d_in = nullptr; c->in_cap = 0;
+        if (hipMalloc(&c->d_in, need_in * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+        c->in_cap = need_in;
+    }
+    HIP_TRY(hipMemcpy(c->d_in, s, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_in + n, theta, n * sizeof(double), hipMemcpyHostToDevice));
+    const double *dp[2] = { nullptr, nullptr };
+    for (int k = 0; k < np; k++) {
+        HIP_TRY(hipMemcpy(c->d_in + (size_t) (2 + k) * n, params[k], n * sizeof(double), hipMemcpyHostToDevice));
+        dp[k] = c->d_in + (size_t) (2 + k) * n;
+    }
+    double *d_res = c->d_in + (size_t) (2 + np) * n;
+    const int rc = rimphony_highfreq_batch_device(c, kind, n, c->d_in, c->d_in + n, dp, d_res, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_res, n * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return RIMPHONY_OK;
+}
+
 extern "C" int rimphony_bessel_batch_device(rimphony_ctx *c, size_t count, const double *d_n, const double *d_x,
                                             double *d_j, double *d_dj, void *stream)
 {

@@ -135,12 +135,35 @@ private:
     std::vector<double> params_;
 };
 
+// `high_freq_approximation()` of the reference (power_law.rs:117-170, thermal_juettner.rs:78-142): the closed-form
+// (Faraday, Q) and (Faraday, V); every other coefficient is NaN.
+class HighFrequencyApproximation {
+public:
+    HighFrequencyApproximation(std::shared_ptr<Context> ctx, int kind, std::vector<double> params)
+        : ctx_(std::move(ctx)), kind_(kind), params_(std::move(params)) {}
+    double compute_dimensionless(Coefficient coeff, Stokes stokes, double s, double theta) const
+    {
+        if (coeff != Coefficient::Faraday || stokes == Stokes::I) return std::numeric_limits<double>::quiet_NaN();
+        std::vector<const double *> pp;
+        for (const double &p : params_) pp.push_back(&p);
+        double out[2];
+        check(rimphony_highfreq_batch(ctx_->get(), kind_, 1, &s, &theta, pp.data(), out), "rimphony_highfreq_batch");
+        return stokes == Stokes::Q ? out[0] : out[1];
+    }
+private:
+    std::shared_ptr<Context> ctx_;
+    int kind_;
+    std::vector<double> params_;
+};
+
 class PowerLawDistribution {
 public:
     explicit PowerLawDistribution(double p) : p_(p) {}
     PowerLawDistribution &gamma_limits(double gmin, double gmax, double gcut) { gmin_ = gmin; gmax_ = gmax; gcut_ = gcut; return *this; }
     FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
     { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_POWER_LAW, {p_, gmin_, gmax_, gcut_}); }
+    HighFrequencyApproximation high_freq_approximation(std::shared_ptr<Context> ctx) const
+    { return HighFrequencyApproximation(std::move(ctx), RIMPHONY_POWER_LAW, {p_, gmin_}); }
 private:
     double p_, gmin_ = 1., gmax_ = 1e12, gcut_ = 1e10;     // defaults: power_law.rs:71-79
 };
@@ -150,6 +173,8 @@ public:
     explicit ThermalJuettnerDistribution(double t) : t_(t) {}
     FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
     { return FullSynchrotronCalculator(std::move(ctx), RIMPHONY_THERMAL_JUETTNER, {t_}); }
+    HighFrequencyApproximation high_freq_approximation(std::shared_ptr<Context> ctx) const
+    { return HighFrequencyApproximation(std::move(ctx), RIMPHONY_THERMAL_JUETTNER, {t_}); }
 private:
     double t_;
 };
