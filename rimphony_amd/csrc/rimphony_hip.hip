@@ -26,27 +26,7 @@
 
 using namespace rim;
 
-// LDS subinterval-store capacities.  Largest counts seen on the reference's golden file and
-// on the bench tables: 31 (gamma integrals), 41 (n chunks), 48 (normalisation).
-#ifndef CAP_INNER
-#define CAP_INNER 64
-#endif
-#ifndef CAP_OUTER
-#define CAP_OUTER 64
-#endif
-#define CAP_NORM 256
-// per-wave global spill behind the LDS stores: the GSL limits of the path (5000 inner for
-// Symphony, 4096 for Heyvaerts, 1000 / 4096 outer)
-#define SPILL_INNER 5000
-#define SPILL_OUTER 4096
-#define SPILL_DOUBLES_PER_WAVE (RIM_ISTORE_DOUBLES(SPILL_INNER) + RIM_ISTORE_DOUBLES(SPILL_OUTER))
-// minimum waves per SIMD the register allocator must leave room for (symphony kernel)
-// (measured on MI355X, 65536-point launches: 4 -> 25.8k, 5 -> 27.0k, 6 -> 27.8k points/s; at 6 the
-// allocator spills 47 VGPRs to scratch and still wins)
-#ifndef RIM_SYM_WAVES
-#define RIM_SYM_WAVES 6
-#define RIM_HEY_WAVES 5          // heyvaerts: 96 VGPRs (2..6 measured: 869, 708, 653, 626, 646 ms on the 8192-point power-law batch)
-#endif
+#include "rimphony_internal.h"
 
 // ------------------------------------------------------------------------------
 // normalisation integrands (power_law.rs:95-96, pitchy_kappa.rs:100-104; the
@@ -169,11 +149,6 @@ struct SymArgs {
     unsigned long long hb_task;
 };
 
-#if defined(RIM_PROF)
-#define RIM_DYN_LDS 256             // the region timers accumulate in dynamic LDS
-#else
-#define RIM_DYN_LDS 0
-#endif
 #if defined(RIM_PROF)
 #define RIM_PROF_ROWS 32768
 __device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 32];
@@ -840,11 +815,6 @@ __global__ void bessel_kernel(size_t count, const double *n, const double *x, do
     if (dj) dj[i] = bessel_dj(n[i], x[i]);
 }
 
-struct PointArgs {
-    double par[5];
-    double s, theta;
-    int coeff, stokes, negative_lobe;
-};
 
 template <int KIND>
 __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const double *norm_ptr, size_t count,
@@ -879,137 +849,6 @@ __global__ __launch_bounds__(64) void gamma_integral_kernel(PointArgs pa, const 
         if (g.lane == 0) out[i] = (q.status == QAG_SUCCESS) ? q.result : RIM_NAN;
     }
 }
-
-// diagnostic_symphony_n_integral (lib.rs:254-260): one outer QAG over n in [n_lo, n_hi] of the gamma-integral,
-// run through the same post / evaluate / consume steps as a chunk of n_integration.
-template <int KIND>
-__global__ __launch_bounds__(64) void n_integral_kernel(PointArgs pa, const double *norm_ptr, size_t count,
-                                                        const double *n_lo, const double *n_hi, double *out, double *spill_base)
-{
-    __shared__ double s_tab[96];
-    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
-    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
-    __shared__ TaskState s_park;
-    const GKLane g = gk_lane_init(s_tab);
-    double *spill = spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
-    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
-    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
-    __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
-    SymPoint pt;
-    pt.s = pa.s;
-    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
-    pt.coeff = pa.coeff;
-    pt.stokes = pa.stokes;
-    DistParams d;
-    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
-    dist_prepare<KIND>(d, norm_ptr[0]);
-    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
-        TaskState T;
-        sym_begin(pt, T);
-        T.phase = PH_QAG_FIRST;
-        T.lobe = pa.negative_lobe;
-        T.qa = uni(n_lo[i]);
-        T.qb = uni(n_hi[i]);
-        T.ni_failed = 0;
-        qag_begin(T.oq, 0., 1e-3, 1000);
-        while (T.phase == PH_QAG_FIRST || T.phase == PH_QAG_BISECT) {
-            SymBatch B;
-            if (!sym_post(pt, g, outer, T, B)) break;
-            __syncthreads();
-            if (g.lane == 0) s_park = T;
-            int batch_status = 0;
-            double gval = 0.;
-            unsigned long long mask = wv_ballot(B.req_active);
-            while (mask) {
-                const int k = __builtin_ffsll((long long) mask) - 1;
-                mask &= mask - 1;
-                const double n = readlane_d(B.req_n, k);
-                const int lb = wv_readlane(B.req_lobe, k);
-                const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, batch_status);
-                if (g.lane == k) gval = val;
-            }
-            __syncthreads();
-            T = s_park;
-            task_uniformize(T);
-            sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
-        }
-        // sym_consume has run the chunk's epilogue: contrib holds the QAG value, ni_failed an Err
-        if (g.lane == 0) out[i] = (T.ni_failed || (T.status & ST_OUTER_FAIL)) ? RIM_NAN : T.contrib;
-    }
-}
-
-// diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567): all harmonics n at fixed gamma.
-// One wave per gamma; the integrand is sampled in n, so every lane carries its own order data (registers/scratch,
-// as in integrand_kernel_n).  Discrete sums are accumulated by lane 0 in the reference's order.
-template <int KIND>
-__global__ __launch_bounds__(64) void gamma_contribution_kernel(PointArgs pa, const double *norm_ptr, size_t count,
-                                                                const double *gammas, double *out, double *spill_base)
-{
-    __shared__ double s_tab[96];
-    __shared__ double s_store[RIM_ISTORE_DOUBLES(CAP_INNER)];
-    __shared__ double s_buf[64];
-    const GKLane g = gk_lane_init(s_tab);
-    const IStore st = istore_carve(s_store, CAP_INNER, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
-    __shared__ QagPark s_qpark;
-    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
-    SymPoint pt;
-    pt.s = pa.s;
-    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
-    pt.coeff = pa.coeff;
-    pt.stokes = pa.stokes;
-    DistParams d;
-    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
-    dist_prepare<KIND>(d, norm_ptr[0]);
-    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const double gamma = uni(gammas[i]);
-        const double delta = rim_fabs(pt.cos_th) * rim_sqrt(gamma * gamma - 1.);
-        const long long n_minus = sat_i64(pt.s * (gamma - delta) + 1.);
-        const long long n_plus = sat_i64(pt.s * (gamma + delta));
-        const bool fully_discrete = n_plus - n_minus < 1000;
-        const long long disc_end = fully_discrete ? n_plus + 1 : n_minus + 31;     // exclusive
-        double ans = 0.;
-        for (long long base = n_minus; base < disc_end; base += 64) {
-            const long long nn = base + g.lane;
-            double v = 0.;
-            if (nn < disc_end) {
-                LeungOrder ord[2];
-                const SymOrder so = sym_order((double) nn, ord);
-                v = gamma_integrand<KIND>(pt, d, so, gamma);
-            }
-            __syncthreads();
-            s_buf[g.lane] = v;
-            __syncthreads();
-            const long long left = disc_end - base;
-            const int cnt = left < 64 ? (int) left : 64;
-            for (int k = 0; k < cnt; k++) ans += s_buf[k];
-        }
-        if (!fully_discrete) {
-            auto f = [&](double n, bool active) -> double {
-                if (!active) return 0.;
-                LeungOrder ord[2];
-                const SymOrder so = sym_order(n, ord);
-                return gamma_integrand<KIND>(pt, d, so, gamma);
-            };
-            QagState q;
-            wave_qag(f, g, st, (double) (n_minus + 31), (double) n_plus, 0., 1e-3, 5000, q, &s_qpark);
-            ans += (q.status == QAG_SUCCESS) ? q.result : RIM_NAN;
-        }
-        double res = RIM_NAN;
-        if (rim_isfinite(ans)) {
-            const double tpe = RIM_TWO_PI * RIM_ELECTRON_CHARGE;
-            const double acos_th = rim_fabs(pt.cos_th);
-            res = (pt.coeff == COEFF_EMISSION) ? ans * ((tpe * tpe) / (RIM_SPEED_LIGHT * acos_th))
-                                               : ans * (-1. * (tpe * tpe) / (2. * RIM_MASS_ELECTRON * RIM_SPEED_LIGHT * acos_th));
-        }
-        if (g.lane == 0) out[i] = res;
-    }
-}
-
-extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
-                                                int coeff, int stokes, int negative_lobe, double s, double theta,
-                                                size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out,
-                                                void *stream);
 
 __device__ inline double selftest_integrand(int family, double p0, double p1, double x)
 {
@@ -1087,15 +926,6 @@ struct rimphony_ctx {
     unsigned long long *hb_dev;
     unsigned long long hb_task;
 };
-
-#define HIP_TRY(expr)                                                            \
-    do {                                                                         \
-        hipError_t e_ = (expr);                                                  \
-        if (e_ != hipSuccess) {                                                  \
-            fprintf(stderr, "rimphony_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
-            return RIMPHONY_EHIP;                                                \
-        }                                                                        \
-    } while (0)
 
 static const int NPARAMS[4] = { 4, 1, 5, 4 };
 
@@ -1673,6 +1503,23 @@ extern "C" int rimphony_gamma_integrand_batch_device(rimphony_ctx *c, int kind, 
     return RIMPHONY_OK;
 }
 
+// helpers shared with rimphony_diag.hip (rimphony_internal.h)
+int rim_point_setup(rimphony_ctx *c, int kind, const double *params, int coeff, int stokes, int negative_lobe,
+                    double s, double theta, hipStream_t st, PointArgs &pa)
+{
+    int rc = fill_point_args(kind, params, coeff, stokes, negative_lobe, s, theta, pa);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return single_point_norm(c, kind, params, st);
+}
+int rim_wave_grid(rimphony_ctx *c, size_t count, int waves_per_cu, unsigned *grid)
+{
+    *grid = persistent_grid(c, count, waves_per_cu);
+    return ensure_spill(c, *grid);
+}
+const double *rim_ctx_norm(const rimphony_ctx *c) { return c->d_norm; }
+double *rim_ctx_spill(const rimphony_ctx *c) { return c->d_spill; }
+
 extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
                                                     int coeff, int stokes, int negative_lobe, double s, double theta,
                                                     size_t count, const double *d_n, double *d_out, void *stream)
@@ -1694,59 +1541,6 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     case 1: hipLaunchKernelGGL(gamma_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     case 2: hipLaunchKernelGGL(gamma_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
     default: hipLaunchKernelGGL(gamma_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n, d_out, c->d_spill); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return RIMPHONY_OK;
-}
-
-extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const double *params,
-                                                int coeff, int stokes, int negative_lobe, double s, double theta,
-                                                size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out,
-                                                void *stream)
-{
-    if (!c || (count && (!d_n_lo || !d_n_hi || !d_out))) return RIMPHONY_EINVAL;
-    PointArgs pa;
-    int rc = fill_point_args(kind, params, coeff, stokes, negative_lobe, s, theta, pa);
-    if (rc) return rc;
-    if (count == 0) return RIMPHONY_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t) stream;
-    rc = single_point_norm(c, kind, params, st);
-    if (rc) return rc;
-    const unsigned grid = persistent_grid(c, count, 16);
-    rc = ensure_spill(c, grid);
-    if (rc) return rc;
-    switch (kind) {
-    case 0: hipLaunchKernelGGL(n_integral_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
-    case 1: hipLaunchKernelGGL(n_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
-    case 2: hipLaunchKernelGGL(n_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
-    default: hipLaunchKernelGGL(n_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_n_lo, d_n_hi, d_out, c->d_spill); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return RIMPHONY_OK;
-}
-
-extern "C" int rimphony_gamma_contribution_batch_device(rimphony_ctx *c, int kind, const double *params, int coeff, int stokes,
-                                                        double s, double theta, size_t count, const double *d_gamma,
-                                                        double *d_out, void *stream)
-{
-    if (!c || (count && (!d_gamma || !d_out))) return RIMPHONY_EINVAL;
-    PointArgs pa;
-    int rc = fill_point_args(kind, params, coeff, stokes, 0, s, theta, pa);
-    if (rc) return rc;
-    if (count == 0) return RIMPHONY_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t) stream;
-    rc = single_point_norm(c, kind, params, st);
-    if (rc) return rc;
-    const unsigned grid = persistent_grid(c, count, 8);
-    rc = ensure_spill(c, grid);
-    if (rc) return rc;
-    switch (kind) {
-    case 0: hipLaunchKernelGGL(gamma_contribution_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_gamma, d_out, c->d_spill); break;
-    case 1: hipLaunchKernelGGL(gamma_contribution_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_gamma, d_out, c->d_spill); break;
-    case 2: hipLaunchKernelGGL(gamma_contribution_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_gamma, d_out, c->d_spill); break;
-    default: hipLaunchKernelGGL(gamma_contribution_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, c->d_norm, count, d_gamma, d_out, c->d_spill); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
