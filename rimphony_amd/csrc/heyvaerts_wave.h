@@ -171,7 +171,7 @@ __device__ __forceinline__ void hey_eval_pair(const HeyPoint &pt, const DistPara
     val0 = 0.; val1 = 0.;
     if (!todo0 && !todo1) return;
 
-    auto f = [&](double v, bool active, bool second) -> double {
+    auto f = [&](double v, bool active, bool second) __attribute__((always_inline)) -> double {
         return active ? hey_element<KIND>(pt, dist, hc, second ? q1 : q0, second ? u1 : u0, v) : 0.;
     };
     // both: one joint run.  Only one of them: it runs as "integral 0" (flip maps it to its own data).

@@ -285,7 +285,7 @@ __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistPara
     n0 = uni(n0); n1 = uni(n1);
     RIM_PROF_ADD(7, t_setup);
 
-    auto f = [&](double x, bool active, bool second) -> double {
+    auto f = [&](double x, bool active, bool second) __attribute__((always_inline)) -> double {
         SymOrder so;
         const int fl = second ? fl1 : fl0;
         so.n = second ? n1 : n0;
