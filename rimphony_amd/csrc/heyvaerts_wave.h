@@ -121,7 +121,7 @@ __device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, co
     } else if (T.phase == HP_QAG_FIRST) {
         const double center = 0.5 * (T.qa + T.qb);
         const double hl = 0.5 * (T.qb - T.qa);
-        B.req_n = center + hl * g.t;
+        B.req_n = center + hl * gk_t(g);
         B.req_active = g.node && g.half == 0;
     } else {
         qag_pick(T.oq, outer, lane);
@@ -129,7 +129,7 @@ __device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, co
         const double lb = g.half ? T.oq.b2 : T.oq.b1;
         const double center = 0.5 * (la + lb);
         const double hl = 0.5 * (lb - la);
-        B.req_n = center + hl * g.t;
+        B.req_n = center + hl * gk_t(g);
         B.req_active = g.node;
     }
     return true;

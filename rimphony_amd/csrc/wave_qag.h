@@ -61,10 +61,13 @@ __constant__ double c_gk_wk[32] = RIM_GK31_WK;
 __constant__ double c_gk_wg[32] = RIM_GK31_WG;
 
 struct GKLane {
-    double t, wk, wg;   // abscissa in [-1, 1], Kronrod weight, Gauss weight of this lane's node
+    const double *tab;  // LDS image of the rule: [0..31] abscissae, [32..63] Kronrod weights, [64..95] Gauss weights
     int lane, half, j;
     bool node;          // j < 31
 };
+__device__ __forceinline__ double gk_t(const GKLane &g) { return g.tab[g.j]; }
+__device__ __forceinline__ double gk_wk(const GKLane &g) { return g.tab[32 + g.j]; }
+__device__ __forceinline__ double gk_wg(const GKLane &g) { return g.tab[64 + g.j]; }
 
 // LDS image of the rule + per-lane registers.  tab must hold 96 doubles.
 __device__ __forceinline__ GKLane gk_lane_init(double *tab)
@@ -80,9 +83,7 @@ __device__ __forceinline__ GKLane gk_lane_init(double *tab)
         tab[64 + g.lane] = c_gk_wg[g.lane];
     }
     wv_sync();
-    g.t = tab[g.j];
-    g.wk = tab[32 + g.j];
-    g.wg = tab[64 + g.j];
+    g.tab = tab;
     return g;
 }
 
@@ -139,11 +140,12 @@ __device__ __forceinline__ double rescale_error(double err, double result_abs, d
 // half_length is the lane's interval half-length (uniform within a half-wave).
 __device__ __forceinline__ GKRes wave_gk31(double fv, double half_length, const GKLane &g)
 {
-    double rk = half_sum(g.wk * fv);
-    const double rg = half_sum(g.wg * fv);
-    double ra = half_sum(g.wk * rim_fabs(fv));
+    const double wk = gk_wk(g);
+    double rk = half_sum(wk * fv);
+    const double rg = half_sum(gk_wg(g) * fv);
+    double ra = half_sum(wk * rim_fabs(fv));
     const double mean = rk * 0.5;
-    double rasc = half_sum(g.wk * rim_fabs(fv - mean));
+    double rasc = half_sum(wk * rim_fabs(fv - mean));
     const double ahl = rim_fabs(half_length);
     const double err = (rk - rg) * half_length;
     rk *= half_length;
@@ -458,7 +460,7 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
         {
             const double center = 0.5 * (la + lb);
             const double hl = 0.5 * (lb - la);
-            const double x = center + hl * g.t;
+            const double x = center + hl * gk_t(g);
             if (g.lane == 0) {
                 park->q = q;
                 park->ctr.samples += first ? 31 : 62;
@@ -545,7 +547,7 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
             active = g.node;
         }
         const double hl = 0.5 * (lb - la);
-        const double x = 0.5 * (la + lb) + hl * g.t;
+        const double x = 0.5 * (la + lb) + hl * gk_t(g);
         if (lane == 0) {
             // only what is live across the integrand (qag_uniformize_live reads exactly these back)
             QagState &pq = park->q;
