@@ -41,7 +41,6 @@ def test_golden_file_subset(oracle):
     assert rel.max() < 0.01, rel.max()
 
 
-@pytest.mark.skipif(not os.environ.get("RIMPHONY_SLOW"), reason="full golden file: set RIMPHONY_SLOW=1 (~20 s on 8 cores)")
 def test_golden_file_full(oracle):
     rows = np.loadtxt(GOLD)
     rel = _golden(oracle, rows)
