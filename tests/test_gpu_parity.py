@@ -230,11 +230,11 @@ def test_all_eight_slots_one_call(gpu_ctx, oracle):
     _symphony_parity(gpu_ctx, oracle, "cfg4_pitchypl_8", 12, 0xFF)
 
 
-def test_golden_file_subset_on_gpu(gpu_ctx):
-    """The reference's own fixture (tests/symphony-powerlaw.txt, Symphony-C values, 1 %)
-    evaluated through the HIP path: every 5th row, all six coefficients."""
+def test_golden_file_on_gpu(gpu_ctx):
+    """The reference's own fixture (tests/symphony-powerlaw.txt, Symphony-C values, 1 %,
+    reference tests/symphony.rs:29-112) evaluated through the HIP path: every row, all six coefficients."""
     import os
-    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "symphony-powerlaw.txt"))[::5]
+    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "symphony-powerlaw.txt"))
     n = len(rows)
     s, th, p = rows[:, 0], rows[:, 1], rows[:, 2]
     out = gpu_ctx.compute_batch(0, s, th, [p, np.ones(n), 1e12 * np.ones(n), 1e10 * np.ones(n)], 0x3F)
@@ -243,7 +243,10 @@ def test_golden_file_subset_on_gpu(gpu_ctx):
     cgs[:, [0, 2, 4]] *= nu
     cgs[:, [1, 3, 5]] /= nu
     rel = np.abs(cgs / rows[:, 3:9] - 1)
-    assert np.nanmax(rel) < 0.01, np.nanmax(rel)
+    assert not np.isnan(rel).any()
+    # same single exception as the oracle's pin (tests/test_oracle.py::test_golden_file_full): alpha_V of row 159
+    bad = np.argwhere(rel >= 0.01)
+    assert len(bad) <= 1 and (len(bad) == 0 or (tuple(bad[0]) == (159, 5) and rel[159, 5] < 0.014)), bad
 
 
 def test_empty_and_unselected(gpu_ctx):
