@@ -267,6 +267,47 @@ def test_results_independent_of_batch_composition(gpu_ctx):
     assert same_bits(full[sub][:, :2], part[:, :2]).all()
 
 
+def test_sharded_table_equals_whole_table_at_bench_size(gpu_ctx):
+    """Size-independent property at the bench's launch size (65536 rows of BASELINE configs[1]): the table
+    computed in one launch and the table assembled from the two interleaved shards a 2-GPU job would compute
+    (row i -> rank i mod 2) are the same bits, NaN rows included."""
+    from rimphony_amd import sharding
+    n = 65536
+    kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", n, start=131072)
+    whole = gpu_ctx.compute_batch(kind, s, th, params, mask)
+    merged = np.empty_like(whole)
+    for rank in range(2):
+        mine = sharding.shard_indices(n, rank, 2)
+        merged[mine] = gpu_ctx.compute_batch(kind, s[mine], th[mine], [p[mine] for p in params], mask)
+    assert same_bits(whole[:, :2], merged[:, :2]).all()
+    assert np.isfinite(whole[:, :2]).mean() > 0.999
+
+
+def test_pitchy_k0_equals_power_law_on_gpu(gpu_ctx):
+    """pitchy_pl.rs:142-201 (k = 0 makes the pitch-angle factor 1): the reference's 5 x 3 choice table plus 256
+    rows of the cfg 2 table, all EIGHT coefficients -- the Faraday pair included, as in the reference's k_zero_rq /
+    k_zero_rv.  The two distributions order the operations of f and df/dgamma differently and normalise through
+    different closed forms, so the bar is north_star's 1e-6 relative, not bit equality."""
+    SS, TH, PS = [1e0, 1e1, 1e2, 1e3, 1e4], [0.05, 0.430, 0.810, 1.190, 1.5707], [1.5, 1.75, 2.5, 3.25, 4.]
+    CH = [1, 4, 2, 3, 1, 0, 0, 3, 1, 2, 0, 4, 4, 2, 3]
+    pts = [(SS[CH[b]], TH[CH[b + 1]], PS[CH[b + 2]]) for b in range(0, 15, 3)]
+    _, _, s2, th2, par2 = workload.make_batch("cfg2_powerlaw_8", 256, start=42000)
+    s = np.concatenate([[q[0] for q in pts], s2])
+    th = np.concatenate([[q[1] for q in pts], th2])
+    p = np.concatenate([[q[2] for q in pts], par2[0]])
+    gmin = np.concatenate([np.ones(len(pts)), par2[1]])
+    n = len(s)
+    gmax, gc = 1e12 * np.ones(n), 1e10 * np.ones(n)
+    a = gpu_ctx.compute_batch(0, s, th, [p, gmin, gmax, gc], 0xFF)
+    b = gpu_ctx.compute_batch(2, s, th, [p, np.zeros(n), gmin, gmax, gc], 0xFF)
+    assert (np.isnan(a) == np.isnan(b)).mean() > 0.99      # a failed quadrature may differ on a borderline row
+    both = np.isfinite(a) & np.isfinite(b)
+    assert both[:len(pts), :6].all()
+    with np.errstate(all="ignore"):
+        rel = np.abs(a / b - 1)
+    assert rel[both].max() < REL_TOL, rel[both].max()
+
+
 def test_cooperative_tail_changes_no_bit(gpu_ctx):
     """The assist board only changes WHO evaluates a gamma-integral / inner integral: a context created with
     RIMPHONY_NO_ASSIST=1 (one wave per task to the end) must return the same bits, status words included, for
