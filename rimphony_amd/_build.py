@@ -7,7 +7,8 @@ matter for correctness (DESIGN.md "Rounding contract"):
       the integrand contains ~300 distinct fp64 literals; gfx9 VOP3 cannot encode
       64-bit literals, and MachineLICM otherwise hoists their materialisation out
       of the quadrature loops into ~200 long-lived VGPRs (256 VGPR + AGPR spills,
-      1 wave/SIMD).  With hoisting off the kernel needs ~150 VGPRs (3 waves/SIMD).
+      1 wave/SIMD).  With hoisting off the constants are rebuilt by the scalar unit
+      next to their use and the Symphony kernel fits 80 VGPRs (6 waves/SIMD).
 """
 import os
 import shutil
