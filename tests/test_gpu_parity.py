@@ -381,6 +381,38 @@ def test_cooperative_tail_changes_no_bit(gpu_ctx):
     assert (st_coop == st_solo).all()
 
 
+def test_hostile_parameter_values_terminate_and_match(gpu_ctx, oracle):
+    """A drop-in gets whatever arrays the caller has: zero / negative / NaN / infinite / out-of-range values of every
+    power-law input, one at a time around a sane point (theta beyond pi/2, gamma_min > gamma_max, cutoff 0 ...).
+    The reference has no input validation -- such points run through the same arithmetic and mostly end as NaN.
+    The launch must end (a persistent kernel that spins on a bad point would hang the caller) and every slot,
+    status word included, must carry the oracle's bits."""
+    nan, inf = float("nan"), float("inf")
+    base = dict(s=10.0, th=0.8, p=2.5, gmin=1.0, gmax=1e12, gc=1e10)
+    hostile = dict(
+        s=[0.0, -1.0, nan, inf, 1e-300, 1e-5, 1e8, 1e12],
+        th=[0.0, -0.5, math.pi / 2, math.pi / 2 + 0.3, 3.0, math.pi, nan, inf, 1e-8, 1e-3],
+        p=[0.0, -2.0, nan, inf, 50.0, 1.0, 0.5],
+        gmin=[0.0, -1.0, 0.5, nan, 1e13, 1.0000001],
+        gmax=[0.5, 1.0, nan, inf, 2.0],
+        gc=[0.0, -1.0, nan, inf, 1e-3, 1.0])
+    pts = []
+    for key, vals in hostile.items():
+        for v in vals:
+            c = dict(base)
+            c[key] = v
+            pts.append(c)
+    col = lambda k: np.array([c[k] for c in pts])
+    s, th = col("s"), col("th")
+    params = [col("p"), col("gmin"), col("gmax"), col("gc")]
+    got, st = gpu_ctx.compute_batch(0, s, th, params, 0xFF, want_status=True)
+    ref = oracle_bind.batch(oracle, 0, s, th, params, 0xFF, nthreads=16)
+    report_mismatch("hostile inputs", got, ref, extra=lambda i: pts[i // 8])
+    nanslot = np.isnan(got)
+    assert ((st & 16) != 0)[nanslot].all() and ((st & 16) == 0)[~nanslot].all()
+    assert np.isfinite(got[len(hostile["s"]) + 3]).all()      # theta = pi/2 + 0.3 is a legitimate angle
+
+
 def test_api_misuse_is_an_error_code_not_a_crash(gpu_ctx):
     """Error convention of the boundary: negative return on misuse, never an abort."""
     import ctypes
