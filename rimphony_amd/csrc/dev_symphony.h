@@ -45,7 +45,22 @@ RIM_DEV void dist_prepare(DistParams &d, double norm)
     if (KIND == DIST_PITCHY_KAPPA) {
         d.inv_kappa_width = 1. / (d.par[0] * d.par[1]);
         d.inv_gamma_cutoff = 1. / d.par[3];
+        // par[4] (unused by this distribution in the C ABI) flags the points whose kappa term may use the
+        // restricted power function: a finite exponent and 1 + (gamma - 1) / (kappa width) a positive normal
+        // number for every gamma >= 1.  Anything else -- kappa = +-inf (1^inf), kappa width < 0 (negative base) --
+        // takes the general rim_pow, as the reference's powf would treat it (tools/hostile_sweep.py).
+        const double kw = d.par[0] * d.par[1];
+        d.par[4] = (rim_isfinite(d.par[0]) && kw > 1e-100 && kw < 1e100) ? 1. : 0.;
     }
+}
+
+// (1 + (gamma - 1) / (kappa width))^-(kappa + 1) of the pitchy-kappa distribution
+RIM_DEV double kappa_gamma_power(const DistParams &d, double gamma)
+{
+    const double base = 1. + (gamma - 1.) * d.inv_kappa_width;
+    const double y = -(d.par[0] + 1.);
+    if (rim_bits(d.par[4]) != 0) return rim_pow_normal(base, y);     // wave-uniform test
+    return rim_pow(base, y);
 }
 
 template <int KIND>
@@ -67,8 +82,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
     } else {
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, d.par[2]);
-        const double gamma_term = rim_pow_normal(1. + (gamma - 1.) * d.inv_kappa_width, -(d.par[0] + 1.)) *
-            rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = kappa_gamma_power(d, gamma) * rim_exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term;
     }
 }
@@ -101,8 +115,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double kappa = d.par[0], width = d.par[1], k = d.par[2];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = rim_pow(sin_xi, k);
-        const double gamma_term = rim_pow_normal(1. + (gamma - 1.) * d.inv_kappa_width, -(kappa + 1.)) *
-            rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = kappa_gamma_power(d, gamma) * rim_exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term;
         dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);

@@ -413,6 +413,33 @@ def test_hostile_parameter_values_terminate_and_match(gpu_ctx, oracle):
     assert np.isfinite(got[len(hostile["s"]) + 3]).all()      # theta = pi/2 + 0.3 is a legitimate angle
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3])
+def test_hostile_parameter_values_other_distributions(gpu_ctx, oracle, kind):
+    """The same for thermal (T), pitchy power law (k) and pitchy kappa (kappa, width, k, cutoff)."""
+    nan, inf = float("nan"), float("inf")
+    if kind == 1:
+        rows = [[T] for T in [0.0, -1.0, nan, inf, 1e-3, 1e-2, 1e4, 1e8]]
+    elif kind == 2:
+        rows = [[2.5, k, 1.0, 1e12, 1e10] for k in [-1.0, -3.0, nan, inf, 50.0, 0.0]]
+    else:
+        rows = [[kap, 5.0, 1.0, 1e10] for kap in [0.0, -1.0, nan, inf, 0.5, 100.0]]
+        rows += [[3.0, w, 1.0, 1e10] for w in [0.0, -1.0, nan, inf, 1e-3, 1e6]]
+        rows += [[3.0, 5.0, k, 1e10] for k in [-1.0, nan, inf, 50.0]]
+        rows += [[3.0, 5.0, 1.0, gc] for gc in [0.0, -1.0, nan, inf, 1.0]]
+        # the kappa term leaves the domain of the kernels' restricted power function here (1^inf; a negative base
+        # with an integer exponent, which powf defines): dist_prepare routes such points to the general rim_pow
+        rows += [[-3.0, 5.0, 1.0, 1e10], [-inf, 5.0, 1.0, 1e10], [1e-200, -2.5, 1.0, 1e10], [inf, -1.0, 1.0, 1e10],
+                 [inf, inf, 1.0, 1e10], [1e200, 1e200, 1.0, 1e10]]
+    n = len(rows)
+    params = [np.array([r[j] for r in rows]) for j in range(len(rows[0]))]
+    s, th = np.full(n, 10.0), np.full(n, 0.8)
+    got, st = gpu_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    ref = oracle_bind.batch(oracle, kind, s, th, params, 0xFF, nthreads=16)
+    report_mismatch("hostile inputs, kind %d" % kind, got, ref, extra=lambda i: rows[i // 8])
+    nanslot = np.isnan(got)
+    assert ((st & 16) != 0)[nanslot].all() and ((st & 16) == 0)[~nanslot].all()
+
+
 def test_api_misuse_is_an_error_code_not_a_crash(gpu_ctx):
     """Error convention of the boundary: negative return on misuse, never an abort."""
     import ctypes

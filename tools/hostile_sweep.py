@@ -1,0 +1,53 @@
+"""Hostile parameter values through the HIP path and the oracle: print every row whose bits differ.
+GPU box only (tests/oracle_bind.py is test infrastructure)."""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_bind  # noqa: E402
+from rimphony_amd import api  # noqa: E402
+
+nan, inf = float("nan"), float("inf")
+WEIRD = [0.0, -0.0, -1.0, -2.5, -3.0, nan, inf, -inf, 1e-320, 1e-200, 1e-30, 1e-3, 0.5, 1.0, 2.0, 50.0, 1e6, 1e30, 1e200]
+SANE = {0: [2.5, 1.0, 1e12, 1e10], 1: [3.0], 2: [2.5, 1.0, 1.0, 1e12, 1e10], 3: [3.0, 5.0, 1.0, 1e10]}
+
+
+def main():
+    ctx = api.Context(0)
+    L = oracle_bind.load("det")
+    total_bad = 0
+    for kind in (0, 1, 2, 3):
+        rows = []
+        for j in range(len(SANE[kind])):
+            for v in WEIRD:
+                r = list(SANE[kind]); r[j] = v
+                rows.append((10.0, 0.8, r))
+        for sv in WEIRD:
+            rows.append((sv, 0.8, list(SANE[kind])))
+        for tv in WEIRD + [np.pi / 2, np.pi / 2 + 0.3, 3.0, np.pi]:
+            rows.append((10.0, tv, list(SANE[kind])))
+        if kind == 3:      # pairs of bad kappa x width
+            for a, b in itertools.product([-2.5, -1.0, 1e-200, 1e200, inf], repeat=2):
+                rows.append((10.0, 0.8, [a, b, 1.0, 1e10]))
+        n = len(rows)
+        s = np.array([r[0] for r in rows]); th = np.array([r[1] for r in rows])
+        params = [np.array([r[2][j] for r in rows]) for j in range(len(SANE[kind]))]
+        got, st = ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+        print("kind", kind, "gpu done", flush=True)
+        ref = oracle_bind.batch(L, kind, s, th, params, 0xFF, nthreads=16)
+        same = (got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))
+        bad = np.flatnonzero(~same.all(axis=1))
+        total_bad += len(bad)
+        print("kind", kind, "rows", n, "rows with a differing slot:", len(bad), flush=True)
+        for i in bad:
+            print("   ", rows[i], "slots", np.flatnonzero(~same[i]).tolist(), "gpu", got[i][~same[i]][:3], "ref", ref[i][~same[i]][:3])
+    print("TOTAL differing rows", total_bad)
+
+
+if __name__ == "__main__":
+    main()
