@@ -18,8 +18,8 @@ SANE = {0: [2.5, 1.0, 1e12, 1e10], 1: [3.0], 2: [2.5, 1.0, 1.0, 1e12, 1e10], 3: 
 
 
 def main():
-    ctx = api.Context(0)
     L = oracle_bind.load("det")
+    ctx = None if os.environ.get("HOSTILE_ORACLE_ONLY") else api.Context(0)     # CPU pre-flight: does the oracle end?
     total_bad = 0
     for kind in (0, 1, 2, 3):
         rows = []
@@ -34,6 +34,20 @@ def main():
         if kind == 3:      # pairs of bad kappa x width
             for a, b in itertools.product([-2.5, -1.0, 1e-200, 1e200, inf], repeat=2):
                 rows.append((10.0, 0.8, [a, b, 1.0, 1e10]))
+        # random combinations: every input drawn from the weird values with probability 1/3, else sane-ish
+        rng = np.random.default_rng(int(os.environ.get("HOSTILE_SEED", "1000")) + kind)
+        for _ in range(int(os.environ.get("HOSTILE_COMBOS", "300"))):
+            pick = lambda sane: float(rng.choice(WEIRD)) if rng.random() < 1 / 3 else sane
+            r = [pick(v * float(np.exp(rng.normal(0, 0.3)))) for v in SANE[kind]]
+            rows.append((pick(float(np.exp(rng.uniform(np.log(0.1), np.log(1e4))))), pick(float(rng.uniform(0.05, 1.52))), r))
+        if os.environ.get("HOSTILE_ORACLE_ONLY"):
+            import time
+            s = np.array([r[0] for r in rows]); th = np.array([r[1] for r in rows])
+            params = [np.array([r[2][j] for r in rows]) for j in range(len(SANE[kind]))]
+            t0 = time.time()
+            ref = oracle_bind.batch(L, kind, s, th, params, 0xFF, nthreads=8)
+            print("kind", kind, "rows", len(rows), "oracle %.1f s" % (time.time() - t0), "finite", int(np.isfinite(ref).sum()), flush=True)
+            continue
         n = len(rows)
         s = np.array([r[0] for r in rows]); th = np.array([r[1] for r in rows])
         params = [np.array([r[2][j] for r in rows]) for j in range(len(SANE[kind]))]
