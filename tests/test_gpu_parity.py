@@ -249,6 +249,19 @@ def test_golden_file_on_gpu(gpu_ctx):
     assert len(bad) <= 1 and (len(bad) == 0 or (tuple(bad[0]) == (159, 5) and rel[159, 5] < 0.014)), bad
 
 
+def test_golden_rows_bit_exact_vs_oracle(gpu_ctx, oracle):
+    """The golden file's parameter rows reach corners the synthetic tables avoid (theta down to 0.0027, s from
+    0.07 to 9433): every 4th row, six coefficients, HIP path against the oracle bit for bit."""
+    import os
+    rows = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "symphony-powerlaw.txt"))[::4]
+    n = len(rows)
+    s, th, p = rows[:, 0].copy(), rows[:, 1].copy(), rows[:, 2].copy()
+    params = [p, np.ones(n), 1e12 * np.ones(n), 1e10 * np.ones(n)]
+    got = gpu_ctx.compute_batch(0, s, th, params, 0x3F)
+    ref = oracle_bind.batch(oracle, 0, s, th, params, 0x3F, nthreads=16)
+    report_mismatch("golden rows vs oracle", got[:, :6], ref[:, :6], extra=lambda i: rows[i // 6, :3])
+
+
 def test_empty_and_unselected(gpu_ctx):
     out = gpu_ctx.compute_batch(0, np.zeros(0), np.zeros(0), [np.zeros(0)] * 4, 0x3F)
     assert out.shape == (0, 8)
