@@ -262,6 +262,19 @@ def test_golden_rows_bit_exact_vs_oracle(gpu_ctx, oracle):
     report_mismatch("golden rows vs oracle", got[:, :6], ref[:, :6], extra=lambda i: rows[i // 6, :3])
 
 
+@pytest.mark.parametrize("cfg,n", [("cfg2_powerlaw_8", 64), ("cfg3_thermal_8", 32), ("cfg4_pitchypl_8", 32),
+                                   ("cfg5_pitchykappa_8", 24)])
+def test_small_angle_corner(gpu_ctx, oracle, cfg, n):
+    """The corner the synthetic tables leave out (theta < 0.05, where the harmonics run to huge n):
+    theta log-uniform in [1e-3, 0.05], all eight slots, bit for bit."""
+    kind, _, s, _, params = workload.make_batch(cfg, n, start=900000)
+    u = workload.uniform01(99, np.arange(n), 1)
+    th = np.exp(np.log(1e-3) + u * (np.log(0.05) - np.log(1e-3)))
+    got, st = gpu_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    ref = oracle_bind.batch(oracle, kind, s, th, params, 0xFF, nthreads=16)
+    report_mismatch("small-angle corner " + cfg, got, ref, extra=lambda i: (s[i // 8], th[i // 8]))
+
+
 def test_empty_and_unselected(gpu_ctx):
     out = gpu_ctx.compute_batch(0, np.zeros(0), np.zeros(0), [np.zeros(0)] * 4, 0x3F)
     assert out.shape == (0, 8)
