@@ -1,5 +1,12 @@
 """Hostile parameter values through the HIP path and the oracle: print every row whose bits differ.
-GPU box only (tests/oracle_bind.py is test infrastructure)."""
+GPU box only (tests/oracle_bind.py is test infrastructure).
+
+  (default)              every input of every distribution set to each WEIRD value in turn around a sane point,
+                         then HOSTILE_COMBOS (300) random mixtures of weird and sane values (seed HOSTILE_SEED)
+  HOSTILE_WIDE=1         valid parameters drawn over far wider spans than the synthetic tables
+  HOSTILE_ORACLE_ONLY=1  CPU pre-flight: only check that the oracle ends on every row (run this first -- the
+                         kernels follow the oracle's decisions, so a row the oracle cannot finish would hang a launch)
+"""
 import itertools
 import os
 import sys
@@ -34,9 +41,26 @@ def main():
         if kind == 3:      # pairs of bad kappa x width
             for a, b in itertools.product([-2.5, -1.0, 1e-200, 1e200, inf], repeat=2):
                 rows.append((10.0, 0.8, [a, b, 1.0, 1e10]))
+        if os.environ.get("HOSTILE_WIDE"):
+            # valid but wide: every parameter over a far larger span than the synthetic tables use
+            rng = np.random.default_rng(int(os.environ.get("HOSTILE_SEED", "1000")) + 10 + kind)
+            lu = lambda lo, hi: float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+            rows = []
+            for _ in range(int(os.environ.get("HOSTILE_COMBOS", "300"))):
+                gmin = lu(1, 1e3)
+                if kind == 0:
+                    r = [rng.uniform(1.01, 8), gmin, lu(gmin * 10, 1e12), lu(10, 1e12)]
+                elif kind == 1:
+                    r = [lu(0.01, 1e3)]
+                elif kind == 2:
+                    r = [rng.uniform(1.01, 8), rng.uniform(0, 10), gmin, lu(gmin * 10, 1e12), lu(10, 1e12)]
+                else:
+                    r = [rng.uniform(1.1, 10), lu(0.1, 100), rng.uniform(0, 10), lu(10, 1e12)]
+                th = rng.uniform(0.01, 1.5607)
+                rows.append((lu(0.01, 1e5), th if rng.random() < 0.5 else np.pi - th, [float(v) for v in r]))
         # random combinations: every input drawn from the weird values with probability 1/3, else sane-ish
         rng = np.random.default_rng(int(os.environ.get("HOSTILE_SEED", "1000")) + kind)
-        for _ in range(int(os.environ.get("HOSTILE_COMBOS", "300"))):
+        for _ in range(0 if os.environ.get("HOSTILE_WIDE") else int(os.environ.get("HOSTILE_COMBOS", "300"))):
             pick = lambda sane: float(rng.choice(WEIRD)) if rng.random() < 1 / 3 else sane
             r = [pick(v * float(np.exp(rng.normal(0, 0.3)))) for v in SANE[kind]]
             rows.append((pick(float(np.exp(rng.uniform(np.log(0.1), np.log(1e4))))), pick(float(rng.uniform(0.05, 1.52))), r))
