@@ -283,6 +283,21 @@ def test_empty_and_unselected(gpu_ctx):
     assert st[0, 0] == 0 and (st[0, 1:] & 64).all()
 
 
+def test_any_coefficient_mask_selects_the_same_bits(gpu_ctx):
+    """A slot's value does not depend on which other slots are selected: every single-bit mask, a few mixed ones
+    and the empty mask on 24 pitchy-power-law points against the columns of the 0xFF table; unselected slots are
+    NaN with status NOT_COMPUTED (64)."""
+    kind, _, s, th, params = workload.make_batch("cfg4_pitchypl_8", 24, start=31000)
+    full, st_full = gpu_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    for mask in [1 << k for k in range(8)] + [0x00, 0xC0, 0x3F, 0x55, 0xAA, 0x81]:
+        out, st = gpu_ctx.compute_batch(kind, s, th, params, mask, want_status=True)
+        sel = [k for k in range(8) if mask & (1 << k)]
+        uns = [k for k in range(8) if not mask & (1 << k)]
+        assert same_bits(out[:, sel], full[:, sel]).all(), hex(mask)
+        assert (st[:, sel] == st_full[:, sel]).all(), hex(mask)
+        assert np.isnan(out[:, uns]).all() and ((st[:, uns] & 64) != 0).all(), hex(mask)
+
+
 def test_results_independent_of_batch_composition(gpu_ctx):
     """A point's result must not depend on what else is in the batch (interleaved
     sharding across GPUs relies on this)."""
