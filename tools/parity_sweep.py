@@ -14,6 +14,7 @@ def same(a, b):
     return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
 for cfg, n, mask in (("cfg2_powerlaw_jI_aI", 8192, 0x03), ("cfg2_powerlaw_8", 768, 0xFF), ("cfg3_thermal_8", 768, 0xFF),
                      ("cfg4_pitchypl_8", 512, 0xFF), ("cfg5_pitchykappa_8", 384, 0xFF)):
+    n *= int(os.environ.get("SWEEP_SCALE", "1"))
     kind, _, s, th, params = workload.make_batch(cfg, n, start=int(os.environ.get("SWEEP_START", "300000")))
     t0 = time.perf_counter()
     got, st = ctx.compute_batch(kind, s, th, params, mask, want_status=True)
