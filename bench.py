@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=262144, help="table rows per GPU per step")
     ap.add_argument("--config", default="cfg2_powerlaw_jI_aI")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="points of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="points of the CPU baseline sample (0 = skip)")
     ap.add_argument("--eight-rows", type=int, default=16384,
                     help="rows per GPU of the secondary eight-coefficient step (0 = skip)")
     args = ap.parse_args()
