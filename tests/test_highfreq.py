@@ -1,8 +1,9 @@
 """High-frequency closed-form Faraday approximations: power_law.rs:133-170,
-thermal_juettner.rs:94-142.  The reference has no test or fixture for them and takes K_nu from the un-vendored
-special-fun crate, so the oracle is pinned here against (a) scipy.special.kv for the Bessel functions and (b) an
-independent numpy transcription of the reference's formulas; the HIP kernel is then compared bit for bit with the
-oracle (they share rimphony_amd/csrc/highfreq.h, so that test checks the GPU build, not the formulas)."""
+thermal_juettner.rs:94-142.  The reference pins them with four 1 % known answers (power_law.rs:200-207, 224-231;
+thermal_juettner.rs:174-181, 194-201), checked here for the oracle and, on the GPU, for the HIP kernel.  It takes K_nu
+from the un-vendored special-fun crate, so the oracle is additionally pinned against (a) scipy.special.kv for the
+Bessel functions and (b) an independent numpy transcription of the reference's formulas; the HIP kernel is then
+compared bit for bit with the oracle (they share rimphony_amd/csrc/highfreq.h, so that test checks the GPU build, not the formulas)."""
 import math
 
 import numpy as np
@@ -59,6 +60,36 @@ def test_oracle_matches_reference_formulas():
         q, v = oracle_bind.highfreq(L, 1, [t], s, th)
         rq, rv = ref_thermal(t, s, th)
         assert abs(q - rq) <= 1e-12 * abs(rq) and abs(v - rv) <= 1e-12 * abs(rv)
+
+
+# (kind, params, s, theta, slot, expected): the reference's own known-answer tests, tolerance 1 % of EXPECTED
+REFERENCE_KNOWN_ANSWERS = [
+    (0, [2.5, 10., 1e12, 1e10], 1e4, 0.25 * math.pi, 0, 1.81e-9),      # pl_hs11_high_freq_rho_q
+    (0, [2.5, 10., 1e12, 1e10], 1e4, 0.25 * math.pi, 1, 1.19e-8),      # pl_hs11_high_freq_rho_v
+    (1, [10.], 4e4, 0.4, 0, 4.8081e-11),                               # tj_approx_high_freq_rho_q
+    (1, [0.1], 40., 0.5, 1, 3.064e-4),                                 # tj_approx_high_freq_rho_v
+]
+
+
+def test_reference_known_answers():
+    L = oracle_bind.load("det")
+    for kind, par, s, th, slot, expected in REFERENCE_KNOWN_ANSWERS:
+        got = oracle_bind.highfreq(L, kind, par, s, th)[slot]
+        assert abs(got - expected) < 0.01 * expected, (kind, par, slot, got, expected)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_known_answers():
+    from rimphony_amd import api
+    ctx = api.Context(0)
+    for kind, par, s, th, slot, expected in REFERENCE_KNOWN_ANSWERS:
+        out = ctx.highfreq_batch(kind, [s], [th], [[v] for v in par])
+        assert abs(out[0, slot] - expected) < 0.01 * expected, (kind, par, slot, out[0], expected)
+    # through the calculator interface, as the reference's tests call it
+    apx = api.PowerLawDistribution(2.5).gamma_limits(10., 1e12, 1e10).high_freq_approximation(ctx)
+    q = apx.compute_dimensionless(api.Coefficient.Faraday, api.Stokes.Q, 1e4, 0.25 * math.pi)
+    assert abs(q - 1.81e-9) < 0.01 * 1.81e-9
+    ctx.close()
 
 
 def test_huang_shcherbakov_figure6_value():
