@@ -216,6 +216,18 @@ int rimphony_gamma_contribution_batch_device(rimphony_ctx *ctx, int dist_kind, c
                                              double s, double theta, size_t count, const double *d_gamma, double *d_out,
                                              void *stream);
 
+/* The DistributionFunction trait (lib.rs:111-146): calc_f(gamma, cos_xi) and calc_f_derivatives(gamma, cos_xi) of ONE
+ * distribution (host `params`, kind-specific as above) over device arrays of count (gamma, cos_xi) pairs.  Any of
+ * d_f, d_dfdg, d_dfdcx may be NULL.  norm_override: NaN = the distribution's own normalisation (what
+ * full_calculation computes); any other value is used as the normalisation constant -- the reference's derivative
+ * tests set it to 1 (pitchy_pl.rs:216-217, pitchy_kappa.rs:149-150). */
+int rimphony_calc_f_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params, double norm_override,
+                                 size_t count, const double *d_gamma, const double *d_cos_xi,
+                                 double *d_f, double *d_dfdg, double *d_dfdcx, void *stream);
+/* the same with host buffers (synchronous) */
+int rimphony_calc_f_batch(rimphony_ctx *ctx, int dist_kind, const double *params, double norm_override, size_t count,
+                          const double *gamma, const double *cos_xi, double *f, double *dfdg, double *dfdcx);
+
 /* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1

@@ -250,6 +250,20 @@ class Context:
         torch.cuda.synchronize(self._dev())
         return out.cpu().numpy()
 
+    def calc_f_batch(self, kind, params, gamma, cos_xi, norm=None):
+        """DistributionFunction::calc_f and calc_f_derivatives (lib.rs:111-146) of one distribution over arrays:
+        returns (f, dfdg, dfdcx).  norm=None uses the distribution's own normalisation."""
+        dg, dc = self._as_dev(gamma), self._as_dev(cos_xi)
+        f, a, b = torch.empty_like(dg), torch.empty_like(dg), torch.empty_like(dg)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_calc_f_batch_device(
+            self.handle, kind, par, float("nan") if norm is None else float(norm), dg.numel(),
+            ctypes.c_void_p(dg.data_ptr()), ctypes.c_void_p(dc.data_ptr()), ctypes.c_void_p(f.data_ptr()),
+            ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), self._stream()),
+            "rimphony_calc_f_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return f.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()
+
     def qag_selftest(self, family, p0, p1, a, b, epsabs, epsrel, limit):
         fam = torch.as_tensor(family, dtype=torch.int32).to(self._dev()).contiguous()
         d = [self._as_dev(v) for v in (p0, p1, a, b)]
@@ -336,7 +350,35 @@ class HighFrequencyApproximation:
         return float(out[0, 0 if int(stokes) == int(Stokes.Q) else 1])
 
 
-class PowerLawDistribution:
+class _DistributionFunction:
+    """The DistributionFunction trait (lib.rs:111-146).  `norm` mirrors the public field of the reference's structs:
+    None until set, in which case calc_f uses the normalisation full_calculation would compute."""
+    norm = None
+    ctx = None
+
+    def _kind_params(self):
+        raise NotImplementedError
+
+    def _calc(self, gamma, cos_xi):
+        kind, params = self._kind_params()
+        g, c = np.atleast_1d(np.asarray(gamma, dtype=np.float64)), np.atleast_1d(np.asarray(cos_xi, dtype=np.float64))
+        g, c = np.broadcast_arrays(g, c)
+        out = (self.ctx or default_context()).calc_f_batch(kind, params, np.ascontiguousarray(g), np.ascontiguousarray(c),
+                                                           self.norm)
+        return out if np.ndim(gamma) or np.ndim(cos_xi) else tuple(float(v[0]) for v in out)
+
+    def calc_f(self, gamma, cos_xi):
+        return self._calc(gamma, cos_xi)[0]
+
+    def calc_f_derivatives(self, gamma, cos_xi):
+        _, dfdg, dfdcx = self._calc(gamma, cos_xi)
+        return dfdg, dfdcx
+
+
+class PowerLawDistribution(_DistributionFunction):
+    def _kind_params(self):
+        return POWER_LAW, [self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff]
+
     def __init__(self, p):
         self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff = float(p), 1.0, 1e12, 1e10
 
@@ -351,7 +393,10 @@ class PowerLawDistribution:
         return HighFrequencyApproximation(POWER_LAW, [self.p, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
 
 
-class ThermalJuettnerDistribution:
+class ThermalJuettnerDistribution(_DistributionFunction):
+    def _kind_params(self):
+        return THERMAL_JUETTNER, [self.t]
+
     def __init__(self, t):
         self.t = float(t)
 
@@ -362,7 +407,10 @@ class ThermalJuettnerDistribution:
         return HighFrequencyApproximation(THERMAL_JUETTNER, [self.t], ctx)
 
 
-class PitchyPowerLawDistribution:
+class PitchyPowerLawDistribution(_DistributionFunction):
+    def _kind_params(self):
+        return PITCHY_PL, [self.p, self.k, self.gamma_min, self.gamma_max, self.gamma_cutoff]
+
     def __init__(self, p, k):
         self.p, self.k = float(p), float(k)
         self.gamma_min, self.gamma_max, self.gamma_cutoff = 1.0, 1e12, 1e10
@@ -376,7 +424,10 @@ class PitchyPowerLawDistribution:
             PITCHY_PL, [self.p, self.k, self.gamma_min, self.gamma_max, self.gamma_cutoff], ctx)
 
 
-class PitchyKappaDistribution:
+class PitchyKappaDistribution(_DistributionFunction):
+    def _kind_params(self):
+        return PITCHY_KAPPA, [self.kappa, self.width, self.k, self._gamma_cutoff]
+
     def __init__(self, kappa, width, k):
         self.kappa, self.width, self.k, self._gamma_cutoff = float(kappa), float(width), float(k), 1e10
 

@@ -14,7 +14,7 @@ SYMBOLS = [
     "rimphony_dist_nparams", "rimphony_ctx_create", "rimphony_ctx_destroy", "rimphony_strerror",
     "rimphony_version", "rimphony_last_work", "rimphony_last_symphony_ms", "rimphony_last_faraday_ms", "rimphony_debug_heartbeat", "rimphony_debug_counters", "rimphony_batch_compute_device", "rimphony_batch_compute",
     "rimphony_batch_norm_device", "rimphony_bessel_batch_device", "rimphony_gamma_integrand_batch_device",
-    "rimphony_gamma_integral_batch_device", "rimphony_n_integral_batch_device", "rimphony_gamma_contribution_batch_device", "rimphony_qag_selftest_device", "rimphony_highfreq_batch_device", "rimphony_highfreq_batch", "rimphony_detmath_batch_device", "pkgw_bessel_j", "pkgw_bessel_dj",
+    "rimphony_gamma_integral_batch_device", "rimphony_n_integral_batch_device", "rimphony_gamma_contribution_batch_device", "rimphony_calc_f_batch_device", "rimphony_calc_f_batch", "rimphony_qag_selftest_device", "rimphony_highfreq_batch_device", "rimphony_highfreq_batch", "rimphony_detmath_batch_device", "pkgw_bessel_j", "pkgw_bessel_dj",
 ]
 
 
@@ -85,6 +85,11 @@ def load():
     lib.rimphony_gamma_contribution_batch_device.restype = c_int
     lib.rimphony_gamma_contribution_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_int, c_double, c_double, c_size_t,
                                                              c_void_p, c_void_p, c_void_p]
+    lib.rimphony_calc_f_batch_device.restype = c_int
+    lib.rimphony_calc_f_batch_device.argtypes = [c_void_p, c_int, dp, c_double, c_size_t, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_calc_f_batch.restype = c_int
+    lib.rimphony_calc_f_batch.argtypes = [c_void_p, c_int, dp, c_double, c_size_t, dp, dp, dp, dp, dp]
     lib.rimphony_detmath_batch_device.restype = c_int
     lib.rimphony_detmath_batch_device.argtypes = [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.rimphony_highfreq_batch.restype = c_int

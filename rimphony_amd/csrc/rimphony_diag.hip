@@ -1,5 +1,6 @@
 // rimphony_diag.hip -- the two diagnostic slices of lib.rs:254-298 that need kernels of their own
-// (diagnostic_symphony_n_integral, diagnostic_symphony_gamma_contribution).  See rimphony_internal.h for why
+// (diagnostic_symphony_n_integral, diagnostic_symphony_gamma_contribution) and the DistributionFunction seam
+// (calc_f / calc_f_derivatives over arrays).  See rimphony_internal.h for why
 // they are not in rimphony_hip.hip.
 #include "rimphony_internal.h"
 
@@ -180,4 +181,75 @@ extern "C" int rimphony_gamma_contribution_batch_device(rimphony_ctx *c, int kin
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
+}
+
+// ---- DistributionFunction::calc_f / calc_f_derivatives (lib.rs:111-146) over arrays -----------------------
+// One thread per (gamma, cos_xi) pair of ONE distribution.  norm_override: NaN = the distribution's own
+// normalisation (full_calculation), anything else = that value (the reference's derivative tests set norm = 1,
+// pitchy_pl.rs:216-217, pitchy_kappa.rs:149-150).
+template <int KIND>
+__global__ void calc_f_kernel(PointArgs pa, const double *norm_ptr, double norm_override, size_t count,
+                              const double *gamma, const double *cos_xi, double *f, double *dfdg, double *dfdcx)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, rim_isnan(norm_override) ? norm_ptr[0] : norm_override);
+    if (f) f[i] = calc_f<KIND>(d, gamma[i], cos_xi[i]);
+    if (dfdg || dfdcx) {
+        double a, b;
+        calc_f_derivatives<KIND>(d, gamma[i], cos_xi[i], a, b);
+        if (dfdg) dfdg[i] = a;
+        if (dfdcx) dfdcx[i] = b;
+    }
+}
+
+extern "C" int rimphony_calc_f_batch_device(rimphony_ctx *c, int kind, const double *params, double norm_override,
+                                            size_t count, const double *d_gamma, const double *d_cos_xi,
+                                            double *d_f, double *d_dfdg, double *d_dfdcx, void *stream)
+{
+    if (!c || (count && (!d_gamma || !d_cos_xi))) return RIMPHONY_EINVAL;
+    hipStream_t st = (hipStream_t) stream;
+    PointArgs pa;
+    // coefficient / stokes / s / theta play no part in f; any valid values satisfy the argument checks
+    int rc = rim_point_setup(c, kind, params, 0, 0, 0, 1., 1., st, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    const double *norm = rim_ctx_norm(c);
+    const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(calc_f_kernel<0>, grid, block, RIM_DYN_LDS, st, pa, norm, norm_override, count, d_gamma, d_cos_xi, d_f, d_dfdg, d_dfdcx); break;
+    case 1: hipLaunchKernelGGL(calc_f_kernel<1>, grid, block, RIM_DYN_LDS, st, pa, norm, norm_override, count, d_gamma, d_cos_xi, d_f, d_dfdg, d_dfdcx); break;
+    case 2: hipLaunchKernelGGL(calc_f_kernel<2>, grid, block, RIM_DYN_LDS, st, pa, norm, norm_override, count, d_gamma, d_cos_xi, d_f, d_dfdg, d_dfdcx); break;
+    default: hipLaunchKernelGGL(calc_f_kernel<3>, grid, block, RIM_DYN_LDS, st, pa, norm, norm_override, count, d_gamma, d_cos_xi, d_f, d_dfdg, d_dfdcx); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+// host-buffer form of the same (what a host-language mirror of the trait calls)
+extern "C" int rimphony_calc_f_batch(rimphony_ctx *c, int kind, const double *params, double norm_override, size_t count,
+                                     const double *gamma, const double *cos_xi, double *f, double *dfdg, double *dfdcx)
+{
+    if (!c || (count && (!gamma || !cos_xi))) return RIMPHONY_EINVAL;
+    if (count == 0) return rimphony_calc_f_batch_device(c, kind, params, norm_override, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    double *buf = nullptr;
+    if (hipMalloc(&buf, 5 * count * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+    int rc = RIMPHONY_EHIP;
+    do {
+        if (hipMemcpy(buf, gamma, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(buf + count, cos_xi, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        rc = rimphony_calc_f_batch_device(c, kind, params, norm_override, count, buf, buf + count, buf + 2 * count,
+                                          buf + 3 * count, buf + 4 * count, nullptr);
+        if (rc) break;
+        rc = RIMPHONY_EHIP;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (f && hipMemcpy(f, buf + 2 * count, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (dfdg && hipMemcpy(dfdg, buf + 3 * count, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (dfdcx && hipMemcpy(dfdcx, buf + 4 * count, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = RIMPHONY_OK;
+    } while (0);
+    (void) hipFree(buf);
+    return rc;
 }

@@ -13,5 +13,14 @@ int main()
     const double rho_q = PowerLawDistribution(2.5).gamma_limits(10., 1e12, 1e10).high_freq_approximation(ctx)
                              .compute_dimensionless(Coefficient::Faraday, Stokes::Q, 1e4, 0.78539816339744831);
     std::printf("HF rho_Q: %.17g\n", rho_q);
-    return std::fabs(ji / 2.64399749412774e-21 - 1.) < 1e-3 && std::fabs(rho_q - 1.8e-9) < 0.05e-9 ? 0 : 1;
+    // the DistributionFunction trait as pitchy_pl.rs:203-238 uses it: norm = 1, analytic vs forward difference
+    PitchyPowerLawDistribution ppd(2.7, 1.3);
+    ppd.norm = 1.;
+    const double g = 5.5, cx = 0.4, eps = 1e-6;
+    const auto d = ppd.calc_f_derivatives(*ctx, g, cx);
+    const double f0 = ppd.calc_f(*ctx, g, cx);
+    const double ndg = (ppd.calc_f(*ctx, g + eps, cx) - f0) / eps, ndc = (ppd.calc_f(*ctx, g, cx + eps) - f0) / eps;
+    std::printf("dfdg %.10e (numeric %.10e)  dfdcx %.10e (numeric %.10e)\n", d[0], ndg, d[1], ndc);
+    const bool deriv_ok = std::fabs((d[0] - ndg) / ndg) < 1e-4 && std::fabs((d[1] - ndc) / ndc) < 1e-4;
+    return std::fabs(ji / 2.64399749412774e-21 - 1.) < 1e-3 && std::fabs(rho_q - 1.8e-9) < 0.05e-9 && deriv_ok ? 0 : 1;
 }

@@ -10,6 +10,7 @@
 //   ThermalJuettnerDistribution::new(t).full_calculation(..)             thermal_juettner.rs:45-72
 //   PitchyPowerLawDistribution::new(p,k).gamma_limits(..)...             pitchy_pl.rs:73-115
 //   PitchyKappaDistribution::new(kappa,width,k).gamma_cutoff(..)...      pitchy_kappa.rs:70-125
+//   trait DistributionFunction { calc_f, calc_f_derivatives }            lib.rs:111-146
 //
 // plus the batched entry the GPU path exists for: BatchCalculator::compute().
 // Numerical failure is NaN, never an exception (symphony.rs:115-117); API misuse
@@ -156,7 +157,38 @@ private:
     std::vector<double> params_;
 };
 
-class PowerLawDistribution {
+// The DistributionFunction trait (lib.rs:111-146): calc_f and calc_f_derivatives, evaluated by the HIP library.
+// `norm` mirrors the public field of the reference's structs (its tests overwrite it, pitchy_pl.rs:216-217): NaN
+// (the default) means "the normalisation full_calculation computes".
+class DistributionFunction {
+public:
+    virtual ~DistributionFunction() = default;
+    double norm = std::numeric_limits<double>::quiet_NaN();
+    double calc_f(const Context &ctx, double gamma, double cos_xi) const
+    {
+        double f;
+        const std::vector<double> p = abi_params();
+        check(rimphony_calc_f_batch(ctx.get(), abi_kind(), p.data(), norm, 1, &gamma, &cos_xi, &f, nullptr, nullptr),
+              "rimphony_calc_f_batch");
+        return f;
+    }
+    std::array<double, 2> calc_f_derivatives(const Context &ctx, double gamma, double cos_xi) const
+    {
+        std::array<double, 2> d;
+        const std::vector<double> p = abi_params();
+        check(rimphony_calc_f_batch(ctx.get(), abi_kind(), p.data(), norm, 1, &gamma, &cos_xi, nullptr, &d[0], &d[1]),
+              "rimphony_calc_f_batch");
+        return d;
+    }
+protected:
+    virtual int abi_kind() const = 0;
+    virtual std::vector<double> abi_params() const = 0;
+};
+
+class PowerLawDistribution : public DistributionFunction {
+protected:
+    int abi_kind() const override { return RIMPHONY_POWER_LAW; }
+    std::vector<double> abi_params() const override { return {p_, gmin_, gmax_, gcut_}; }
 public:
     explicit PowerLawDistribution(double p) : p_(p) {}
     PowerLawDistribution &gamma_limits(double gmin, double gmax, double gcut) { gmin_ = gmin; gmax_ = gmax; gcut_ = gcut; return *this; }
@@ -168,7 +200,10 @@ private:
     double p_, gmin_ = 1., gmax_ = 1e12, gcut_ = 1e10;     // defaults: power_law.rs:71-79
 };
 
-class ThermalJuettnerDistribution {
+class ThermalJuettnerDistribution : public DistributionFunction {
+protected:
+    int abi_kind() const override { return RIMPHONY_THERMAL_JUETTNER; }
+    std::vector<double> abi_params() const override { return {t_}; }
 public:
     explicit ThermalJuettnerDistribution(double t) : t_(t) {}
     FullSynchrotronCalculator full_calculation(std::shared_ptr<Context> ctx) const
@@ -179,7 +214,10 @@ private:
     double t_;
 };
 
-class PitchyPowerLawDistribution {
+class PitchyPowerLawDistribution : public DistributionFunction {
+protected:
+    int abi_kind() const override { return RIMPHONY_PITCHY_PL; }
+    std::vector<double> abi_params() const override { return {p_, k_, gmin_, gmax_, gcut_}; }
 public:
     PitchyPowerLawDistribution(double p, double k) : p_(p), k_(k) {}
     PitchyPowerLawDistribution &gamma_limits(double gmin, double gmax, double gcut) { gmin_ = gmin; gmax_ = gmax; gcut_ = gcut; return *this; }
@@ -189,7 +227,10 @@ private:
     double p_, k_, gmin_ = 1., gmax_ = 1e12, gcut_ = 1e10;
 };
 
-class PitchyKappaDistribution {
+class PitchyKappaDistribution : public DistributionFunction {
+protected:
+    int abi_kind() const override { return RIMPHONY_PITCHY_KAPPA; }
+    std::vector<double> abi_params() const override { return {kappa_, width_, k_, gcut_}; }
 public:
     PitchyKappaDistribution(double kappa, double width, double k) : kappa_(kappa), width_(width), k_(k) {}
     PitchyKappaDistribution &gamma_cutoff(double gcut) { gcut_ = gcut; return *this; }

@@ -536,10 +536,61 @@ def test_gamma_contribution_diagnostic_bit_exact(gpu_ctx, oracle):
             assert np.isfinite(ref).sum() >= 6
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_distribution_function_seam_bit_exact(gpu_ctx, oracle, kind):
+    """DistributionFunction::calc_f / calc_f_derivatives (lib.rs:111-146) through the C ABI against the oracle's
+    restatement, bit for bit, with the distribution's own normalisation and with norm = 1."""
+    rng = np.random.default_rng(50 + kind)
+    par = {0: [2.7, 3.0, 1e7, 1e5], 1: [4.0], 2: [3.1, 1.4, 2.0, 1e8, 1e6], 3: [3.3, 6.0, 0.8, 1e4]}[kind]
+    n = 512
+    gamma = np.exp(rng.uniform(math.log(1.0001), math.log(2e7), n))
+    cos_xi = rng.uniform(-0.99, 0.99, n)
+    d, st = oracle_bind.mkdist(oracle, kind, par)
+    assert st == 0
+    for norm in (None, 1.0):
+        if norm is not None:
+            d.norm = norm
+        f, dg, dc = gpu_ctx.calc_f_batch(kind, par, gamma, cos_xi, norm)
+        rf = np.array([oracle.rimo_calc_f(d, g, c) for g, c in zip(gamma, cos_xi)])
+        rdg, rdc = np.empty(n), np.empty(n)
+        a, b = ctypes.c_double(), ctypes.c_double()
+        for i in range(n):
+            oracle.rimo_calc_f_derivatives(d, gamma[i], cos_xi[i], ctypes.byref(a), ctypes.byref(b))
+            rdg[i], rdc[i] = a.value, b.value
+        report_mismatch("calc_f kind %d" % kind, f, rf)
+        report_mismatch("dfdg kind %d" % kind, dg, rdg)
+        report_mismatch("dfdcx kind %d" % kind, dc, rdc)
+
+
+@pytest.mark.parametrize("which", ["pitchy_pl", "pitchy_kappa"])
+def test_reference_derivative_tests_on_gpu(gpu_ctx, which):
+    """pitchy_pl.rs:203-238 and pitchy_kappa.rs:135-173 as the reference writes them -- a distribution object,
+    `norm = 1` ("fake this"), calc_f_derivatives against forward differences of calc_f with EPS 1e-6, TOL 1e-4,
+    100 random draws -- with calc_f evaluated by the HIP library."""
+    from rimphony_amd import api
+    rng = np.random.default_rng(3)
+    EPS, TOL = 1e-6, 1e-4
+    for _ in range(100):
+        if which == "pitchy_pl":
+            dist = api.PitchyPowerLawDistribution(2. + 3. * rng.random(), 0. + 3. * rng.random())
+        else:
+            dist = api.PitchyKappaDistribution(1.5 + 3. * rng.random(), math.exp(1. + 2. * rng.random()), 3. * rng.random())
+        dist.ctx = gpu_ctx
+        dist.norm = 1.                                   # fake this
+        gamma, cos_xi = 1.1 + 1e3 * rng.random(), 0.01 + 0.98 * rng.random()
+        analytic_dfdg, analytic_dfdcx = dist.calc_f_derivatives(gamma, cos_xi)
+        f0 = dist.calc_f(gamma, cos_xi)
+        numeric_dfdg = (dist.calc_f(gamma + EPS, cos_xi) - f0) / EPS
+        numeric_dfdcx = (dist.calc_f(gamma, cos_xi + EPS) - f0) / EPS
+        assert abs((analytic_dfdg - numeric_dfdg) / numeric_dfdg) < TOL, (gamma, cos_xi, analytic_dfdg, numeric_dfdg)
+        assert abs((analytic_dfdcx - numeric_dfdcx) / numeric_dfdcx) < TOL, (gamma, cos_xi, analytic_dfdcx, numeric_dfdcx)
+
+
 def test_cxx_mirror_builds_and_runs(tmp_path, gpu_ctx):
     """The header-only C++ mirror of the reference API (rimphony_amd/cxx/rimphony.hpp) over the C ABI: the
-    counterpart of examples/one-powerlaw-direct.rs (j_I within 1e-3 of Symphony's printed value) and a
-    high-frequency closed form; the program exits 0 when both hold."""
+    counterpart of examples/one-powerlaw-direct.rs (j_I within 1e-3 of Symphony's printed value), a
+    high-frequency closed form and one derivative check through the DistributionFunction trait; the program exits
+    0 when all hold."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "one_powerlaw_direct"
