@@ -100,3 +100,30 @@ def test_demo_and_all8_on_gpu(gpu_ctx):
     out = drivers.all_pitchykappa_cgs_lines(lambda dist: dist.full_calculation(gpu_ctx), 1e9, 100., 1., 0.7, 4., 10., 1.)
     vals = [float(ln.split(": ")[1]) for ln in out]
     assert len(vals) == 8 and all(math.isfinite(v) for v in vals) and vals[0] > 0 and vals[1] > 0
+
+
+def test_rust_e_format():
+    """Rust's `{:e}` (one-powerlaw-normalized.rs:43-44 prints with it)."""
+    from rimphony_amd.drivers import rust_e
+    assert [rust_e(x) for x in (0.0, 1.0, 2.64399749412774e-21, 1e9, 123456.789, 0.1, -1.5e-300)] == \
+        ["0e0", "1e0", "2.64399749412774e-21", "1e9", "1.23456789e5", "1e-1", "-1.5e-300"]
+    assert rust_e(float("nan")) == "NaN" and rust_e(float("inf")) == "inf"
+
+
+@pytest.mark.gpu
+def test_one_point_normalized_drivers_on_gpu(gpu_ctx, oracle):
+    """examples/one-pitchypl-normalized.rs and one-powerlaw-normalized.rs: the points their author hard-coded
+    (a small-angle pitchy rho_Q, a high-s power-law alpha_I), through the drivers and against the oracle's bits."""
+    import oracle_bind
+    from rimphony_amd import drivers
+    c = drivers.ONE_PITCHYPL_NORMALIZED
+    line = drivers.one_pitchypl_normalized_lines(lambda dist: dist.full_calculation(gpu_ctx))[0]
+    ref = oracle_bind.batch(oracle, 2, [c["s"]], [c["theta"]], [[c["p"]], [c["k"]], [1.], [1e12], [1e10]], 0x40, nthreads=1)
+    assert line == drivers.rust_e18(ref[0, 6]) and math.isfinite(ref[0, 6])
+    c = drivers.ONE_POWERLAW_NORMALIZED
+    lines = drivers.one_powerlaw_normalized_lines(lambda dist: dist.full_calculation(gpu_ctx))
+    ref = oracle_bind.batch(oracle, 0, [c["s"]], [c["theta"]], [[c["p"]], [1.], [1e12], [1e10]], 0x02, nthreads=1)
+    assert lines[0].startswith("Inner Symphony: ") and lines[1].startswith("Outer Symphony: 0e0   Us: ")
+    us = float(lines[1].split("Us: ")[1])
+    # compute_cgs: alpha * n_e / nu with nu / nu_c = S by the choice of B (B is rounded, so s is S to an ulp or two)
+    assert abs(us / (ref[0, 1] / 1e9) - 1.) < 1e-9 and us > 0
