@@ -275,6 +275,21 @@ def test_small_angle_corner(gpu_ctx, oracle, cfg, n):
     report_mismatch("small-angle corner " + cfg, got, ref, extra=lambda i: (s[i // 8], th[i // 8]))
 
 
+def test_reference_benchmark_cases(gpu_ctx, oracle):
+    """The five rows of the Latin square of benches/powerlaw.rs:28-45 (its sixteen benchmark functions compute one
+    coefficient each on these rows): all eight slots, bit for bit."""
+    SS, TH, PS = [1e0, 1e1, 1e2, 1e3, 1e4], [0.05, 0.430, 0.810, 1.190, 1.5707], [1.5, 1.75, 2.5, 3.25, 4.]
+    LATIN = [1, 4, 2, 3, 0, 3, 1, 0, 4, 2, 0, 3, 1, 2, 4, 2, 0, 4, 1, 3, 4, 2, 3, 0, 1]
+    s = np.array([SS[LATIN[5 * r + 2]] for r in range(5)])
+    th = np.array([TH[LATIN[5 * r + 3]] for r in range(5)])
+    p = np.array([PS[LATIN[5 * r + 4]] for r in range(5)])
+    params = [p, np.ones(5), 1e12 * np.ones(5), 1e10 * np.ones(5)]
+    got = gpu_ctx.compute_batch(0, s, th, params, 0xFF)
+    ref = oracle_bind.batch(oracle, 0, s, th, params, 0xFF, nthreads=5)
+    report_mismatch("benches/powerlaw.rs rows", got, ref, extra=lambda i: (s[i // 8], th[i // 8], p[i // 8]))
+    assert np.isfinite(got[0]).all()          # row 0 carries all eight benchmark functions
+
+
 def test_empty_and_unselected(gpu_ctx):
     out = gpu_ctx.compute_batch(0, np.zeros(0), np.zeros(0), [np.zeros(0)] * 4, 0x3F)
     assert out.shape == (0, 8)
