@@ -72,7 +72,8 @@ def main():
     # Rehearsal switch for 1-GPU boxes: RIMPHONY_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo
     # (the gather then goes through host memory).  The real multi-GPU run uses RCCL ("nccl"), one GPU per rank.
     rehearse = os.environ.get("RIMPHONY_BENCH_REHEARSE") == "1"
-    dev_index = 0 if rehearse else local_rank
+    # one GPU per rank; if a launcher narrowed the visible devices to one per rank, that one is index 0
+    dev_index = 0 if rehearse else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     if distributed:
         if rehearse:
