@@ -118,6 +118,26 @@ def test_gpu_highfreq_bit_exact():
     for i in range(0, n, 7):
         q, v = oracle_bind.highfreq(L, 1, [t[i]], s[i], th[i])
         assert np.array_equal(np.array([q, v]).view(np.uint64), out[i].view(np.uint64)), (i, q, v, out[i])
+    # hostile values (p = 2 divides by zero, gamma_min <= 0, s <= 0, NaN, inf ...): the same bits as the oracle, NaNs included
+    nan, inf = float("nan"), float("inf")
+    weird = [0.0, -1.0, 2.0, nan, inf, -inf, 1e-320, 1e-200, 1e200, 1.0]
+    for kind, sane in ((api.POWER_LAW, [2.5, 10.]), (api.THERMAL_JUETTNER, [10.])):
+        rows = []
+        for j in range(len(sane) + 2):
+            for w in weird:
+                r = [1e4, 0.7] + list(sane)
+                r[j] = w
+                rows.append(r)
+        rows = np.array(rows)
+        par = [rows[:, 2 + k].copy() for k in range(len(sane))]
+        if kind == api.POWER_LAW:
+            par += [np.full(len(rows), 1e12), np.full(len(rows), 1e10)]
+        out = ctx.highfreq_batch(kind, rows[:, 0].copy(), rows[:, 1].copy(), par)
+        for i, r in enumerate(rows):
+            q, v = oracle_bind.highfreq(L, kind, list(r[2:]), r[0], r[1])
+            ref = np.array([q, v])
+            same = (ref.view(np.uint64) == out[i].view(np.uint64)) | (np.isnan(ref) & np.isnan(out[i]))
+            assert same.all(), (kind, list(r), ref, out[i])
     # the calculator interface of the reference: only (Faraday, Q|V) are defined
     calc = api.ThermalJuettnerDistribution(10.).high_freq_approximation(ctx)
     assert math.isnan(calc.compute_dimensionless(api.Coefficient.Emission, api.Stokes.I, 1e5, 0.7))
