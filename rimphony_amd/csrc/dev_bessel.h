@@ -593,6 +593,8 @@ RIM_DEV double meissel_second(double n, double x)
 RIM_DEV double bessel_j(double n, double x)
 {
     if (!(n >= 0 && x >= 0)) return RIM_NAN;
+    x = x + 0.;     // -0 -> +0: the restricted logarithm of meissel_first reads the sign bit as exponent (the integrator
+                    // never passes -0: sym_bessel_pair tests z == 0 first; this is for callers of the seam)
     if (n < 30.) {
         const int n_int = (int) n;
         if (n_int != n) return RIM_NAN;

@@ -60,6 +60,25 @@ def test_bessel_bit_exact(gpu_ctx, oracle):
     report_mismatch("bessel_dj", dj, rdj, lambda i: (n[i], x[i]))
 
 
+def test_bessel_hostile_arguments(gpu_ctx, oracle):
+    """pkgw_bessel_j / pkgw_bessel_dj on every pair of a grid of awkward orders and arguments (zero, negative,
+    fractional below 30, 1e15 and beyond, subnormal, NaN, +-inf; x from 0 to 1e300, negative, NaN, inf): the device
+    function returns what the oracle returns, NaNs included."""
+    import itertools
+    nan, inf = float("nan"), float("inf")
+    ns = [0., 1., 2., 5., 29., 30., 31., 12.5, 30.5, 100., 1e3, 1e6, 1e15, 1e16, 1e300, -1., -30., -100.5, nan, inf, -inf,
+          1e-320, 0.5]
+    xs = [0., -0., 1e-320, 1e-300, 1e-10, 0.5, 1., 5., 17., 29.9, 30., 31., 100., 1e3, 5e4, 5.1e4, 1e6, 1e15, 1e55, 1e56,
+          1e300, -1., -100., -1e-320, -30., -1e6, nan, inf, -inf]
+    pairs = np.array(list(itertools.product(ns, xs)))
+    n, x = pairs[:, 0].copy(), pairs[:, 1].copy()
+    j, dj = gpu_ctx.bessel_batch(n, x)
+    rj = np.array([oracle.rimo_bessel_j(a, b) for a, b in zip(n, x)])
+    rdj = np.array([oracle.rimo_bessel_dj(a, b) for a, b in zip(n, x)])
+    report_mismatch("bessel_j hostile", j, rj, lambda i: (n[i], x[i]))
+    report_mismatch("bessel_dj hostile", dj, rdj, lambda i: (n[i], x[i]))
+
+
 def test_scalar_bessel_seam(gpu_ctx, oracle):
     """pkgw_bessel_j / pkgw_bessel_dj, the reference's own FFI seam (leung-bessel/src/lib.rs:36-42), as exported
     by the library: same bits as the batch entry point and the oracle, NaN conventions included."""
