@@ -596,6 +596,30 @@ def test_distribution_function_seam_bit_exact(gpu_ctx, oracle, kind):
         report_mismatch("dfdcx kind %d" % kind, dc, rdc)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_distribution_function_seam_hostile_arguments(gpu_ctx, oracle, kind):
+    """calc_f / calc_f_derivatives on every pair of awkward gammas (0, below 1, 1, beyond gamma_max, negative, NaN,
+    inf, subnormal) and pitch-angle cosines (+-1, beyond 1, NaN, inf): the oracle's bits (tools/calc_f_hostile.py)."""
+    import itertools
+    nan, inf = float("nan"), float("inf")
+    gs = [0., -0., 0.5, 1., 1.0000000000000002, 1.5, 10., 1e6, 1e12, 1e13, 1e100, 1e300, inf, -1., -inf, nan, 1e-320]
+    cs = [-1., 1., 0., -0., 0.5, -0.5, 0.9999999999999999, 1.5, -1.5, nan, inf, 1e-320]
+    par = {0: [2.7, 1.0, 1e12, 1e10], 1: [4.0], 2: [3.1, 1.4, 1.0, 1e12, 1e10], 3: [3.3, 6.0, 0.8, 1e10]}[kind]
+    pairs = np.array(list(itertools.product(gs, cs)))
+    g, c = pairs[:, 0].copy(), pairs[:, 1].copy()
+    d, st = oracle_bind.mkdist(oracle, kind, par)
+    f, dg, dc = gpu_ctx.calc_f_batch(kind, par, g, c, None)
+    rf = np.array([oracle.rimo_calc_f(d, a, b) for a, b in zip(g, c)])
+    rdg, rdc = np.empty(len(g)), np.empty(len(g))
+    x, y = ctypes.c_double(), ctypes.c_double()
+    for i in range(len(g)):
+        oracle.rimo_calc_f_derivatives(d, g[i], c[i], ctypes.byref(x), ctypes.byref(y))
+        rdg[i], rdc[i] = x.value, y.value
+    report_mismatch("calc_f hostile kind %d" % kind, f, rf, lambda i: (g[i], c[i]))
+    report_mismatch("dfdg hostile kind %d" % kind, dg, rdg, lambda i: (g[i], c[i]))
+    report_mismatch("dfdcx hostile kind %d" % kind, dc, rdc, lambda i: (g[i], c[i]))
+
+
 @pytest.mark.parametrize("which", ["pitchy_pl", "pitchy_kappa"])
 def test_reference_derivative_tests_on_gpu(gpu_ctx, which):
     """pitchy_pl.rs:203-238 and pitchy_kappa.rs:135-173 as the reference writes them -- a distribution object,
