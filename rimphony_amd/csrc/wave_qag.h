@@ -48,7 +48,21 @@ __device__ __forceinline__ int wv_readlane(int v, int srclane) { return __builti
 __device__ __forceinline__ int wv_readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double wv_shfl_xor(double v, int m) { return __shfl_xor(v, m); }
 __device__ __forceinline__ int wv_shfl_xor(int v, int m) { return __shfl_xor(v, m); }
+// The value of lane (lane ^ M), M < 32, by ds_swizzle in bit-mask mode (and 0x1f, or 0, xor M within each group of
+// 32 lanes): the same exchange as wv_shfl_xor(v, M) without the per-step address arithmetic of ds_bpermute
+// (lane ^ M, the bounds select, the shift: 4 VALU issues per distinct M and a live VGPR each).
+template <int M>
+__device__ __forceinline__ double wv_swz_xor(double v)
+{
+    static_assert(M > 0 && M < 32, "ds_swizzle bit-mask mode works within 32 lanes");
+    const unsigned long long u = rim_bits(v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_ds_swizzle((int) (unsigned) u, (M << 10) | 0x1f);
+    const unsigned hi = (unsigned) __builtin_amdgcn_ds_swizzle((int) (unsigned) (u >> 32), (M << 10) | 0x1f);
+    return rim_frombits(((unsigned long long) hi << 32) | lo);
+}
 __device__ __forceinline__ unsigned long long wv_ballot(bool p) { return __ballot(p); }
+#else
+template <int M> inline double wv_swz_xor(double v) { return wv_shfl_xor(v, M); }     // emulator: same exchange
 #endif
 
 enum {
@@ -110,11 +124,11 @@ __device__ __forceinline__ bool uni(bool v) { return wv_readfirstlane((int) v) !
 // Sum over the 32 lanes of each half-wave; all lanes of a half receive the sum.
 __device__ __forceinline__ double half_sum(double v)
 {
-    v = v + wv_shfl_xor(v, 1);
-    v = v + wv_shfl_xor(v, 2);
-    v = v + wv_shfl_xor(v, 4);
-    v = v + wv_shfl_xor(v, 8);
-    v = v + wv_shfl_xor(v, 16);
+    v = v + wv_swz_xor<1>(v);
+    v = v + wv_swz_xor<2>(v);
+    v = v + wv_swz_xor<4>(v);
+    v = v + wv_swz_xor<8>(v);
+    v = v + wv_swz_xor<16>(v);
     return v;
 }
 
@@ -309,8 +323,12 @@ __device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane
         // The largest error first (one max per butterfly step); the (error, stamp) tie-break of the
         // sorted list only matters when two lanes hold that same error, which is rare.
         double top = be;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) top = __builtin_fmax(top, wv_shfl_xor(top, m));
+        top = __builtin_fmax(top, wv_swz_xor<1>(top));
+        top = __builtin_fmax(top, wv_swz_xor<2>(top));
+        top = __builtin_fmax(top, wv_swz_xor<4>(top));
+        top = __builtin_fmax(top, wv_swz_xor<8>(top));
+        top = __builtin_fmax(top, wv_swz_xor<16>(top));
+        top = __builtin_fmax(top, wv_shfl_xor(top, 32));
         const unsigned long long holders = wv_ballot(be == top);
         if (__builtin_popcountll(holders) == 1) {
             bi = wv_readlane(bi, __builtin_ffsll((long long) holders) - 1);
