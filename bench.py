@@ -44,7 +44,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk
 # KB -> bytes; narrow accesses, so the gfx950 "wide read" doubling does not apply) on one 65536-row launch of
 # this table: profiles/r1_final_pmc_symphony_65536pts.json.  Nearly all of it is scratch (register spill)
 # traffic; it scales with the sample count, hence the per-sample figure.  Algorithmic bytes are ~150 B/point.
-PMC_BYTES_PER_SAMPLE = (6.3528e5 + 3.5707e7) * 1024. / 34183156539.
+PMC_BYTES_PER_SAMPLE = (6.504e5 + 3.5443e7) * 1024. / 34183156539.
 
 
 def main():

@@ -11,7 +11,7 @@
 //   * A bisection evaluates BOTH children in one pass: left child on lanes
 //     0..31, right child on lanes 32..63 (62 of 64 lanes busy).
 //   * The four rule sums (Kronrod, Gauss, |f|, |f - mean|) are 5-step xor
-//     butterflies inside each half-wave.  Floating-point addition commutes, so
+//     butterflies inside each half-wave (ds_swizzle, bit-mask mode).  Floating-point addition commutes, so
 //     every lane of a half ends with the same bits: the value of a fixed
 //     balanced binary tree over the 32 lanes.  The CPU oracle sums in the same
 //     tree order, which is what makes results comparable bit for bit.
