@@ -29,7 +29,9 @@
 // allocator spills 47 VGPRs to scratch and still wins)
 #ifndef RIM_SYM_WAVES
 #define RIM_SYM_WAVES 6
-#define RIM_HEY_WAVES 5          // heyvaerts: 96 VGPRs (2..6 measured: 869, 708, 653, 626, 646 ms on the 8192-point power-law batch)
+#define RIM_HEY_WAVES 5          // heyvaerts: 96 VGPRs (2..6 measured: 869, 708, 653, 626, 646 ms on the 8192-point power-law batch;
+                                 // final build, 4 / 5 / 6: 782 / 741 / 718 ms on 16384 power-law points but 993 / 967 / 996 ms on 4096
+                                 // pitchy-kappa points, whose tail is sequential -- 5 kept)
 #endif
 
 #if defined(RIM_PROF)
