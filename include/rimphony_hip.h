@@ -82,6 +82,14 @@ int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unkno
 #define RIMPHONY_EHIP      -2
 #define RIMPHONY_ENOMEM    -3
 #define RIMPHONY_ENODEVICE -4
+#define RIMPHONY_EBUSY     -5   /* RIMPHONY_EXCLUSIVE=1 and another context already has the device */
+#define RIMPHONY_ENOTSUP   -6   /* e.g. a `precision` this build does not implement */
+
+/* `precision` of the _ex / _multi entry points.  F64 is the reference's arithmetic and the only one
+ * implemented; F32_INTEGRAND (BASELINE configs[4]: fp32 integrand, fp64 Kahan accumulation) is reserved and returns
+ * RIMPHONY_ENOTSUP. */
+#define RIMPHONY_PRECISION_F64            0
+#define RIMPHONY_PRECISION_F32_INTEGRAND  1
 
 typedef struct rimphony_ctx rimphony_ctx;
 
@@ -89,10 +97,19 @@ typedef struct rimphony_ctx rimphony_ctx;
  * RIMPHONY_ENODEVICE when no GPU is present (there is no CPU fallback).
  * Environment, read once here: RIMPHONY_NO_ASSIST=1 turns the cooperative tail of the kernels off (one
  * wavefront per task to the end; same results bit for bit, used for A/B measurements and by the tests).
- * A context assumes it has the GPU to itself: its persistent grids fill the device. */
+ * One context per GPU is the supported configuration: its persistent grids fill the device.  The first context
+ * on a device (in any process) takes an exclusive flock on /dev/shm/rimphony_hip.<pci bus id>.lock for its
+ * lifetime; a context created while that lock is held runs in SHARED mode (quarter-size grids, cooperative tail
+ * off: slower, same results) or, with RIMPHONY_EXCLUSIVE=1 in the environment, is refused with RIMPHONY_EBUSY.
+ * Calls on one context are serialised and ordered on the device whatever streams they name; different contexts
+ * may be used from different threads freely. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);
 void rimphony_ctx_destroy(rimphony_ctx *ctx);
+int rimphony_ctx_shared_mode(const rimphony_ctx *ctx);   /* 0: owns the device, 1: shared mode */
 const char *rimphony_strerror(int code);
+/* Text of the most recent failure on the calling thread (which HIP call failed and why); "" if none.  The library
+ * never prints. */
+const char *rimphony_last_error(void);
 const char *rimphony_version(void);
 
 /* Work counters of the most recent batch call on this context (device-side
@@ -153,6 +170,33 @@ int rimphony_batch_compute(rimphony_ctx *ctx, int dist_kind, size_t n,
                            const double *const *params, uint32_t coeff_mask,
                            double *out, int32_t *status);
 
+/* The same two with the remaining arguments of SURVEY 8b's batch ABI:
+ *   precision   RIMPHONY_PRECISION_*
+ *   d_work/work optional [n][8] uint64: integrand samples spent on each coefficient (0 for unselected slots) --
+ *               the per-point counterpart of the reference's per-call trace lines (symphony.rs:69-75, 217-223,
+ *               272-275) and of the crank-out drivers' per-row `time_ms(meta)` column
+ *               (examples/crank-out-pitchypl.rs:167-173): cost in units that do not depend on what else ran. */
+int rimphony_batch_compute_device_ex(rimphony_ctx *ctx, int dist_kind, size_t n,
+                                     const double *d_s, const double *d_theta,
+                                     const double *const *d_params, uint32_t coeff_mask, int precision,
+                                     double *d_out, int32_t *d_status, uint64_t *d_work, void *stream);
+int rimphony_batch_compute_ex(rimphony_ctx *ctx, int dist_kind, size_t n,
+                              const double *s, const double *theta,
+                              const double *const *params, uint32_t coeff_mask, int precision,
+                              double *out, int32_t *status, uint64_t *work);
+
+/* Multi-GPU batch (SURVEY 8b `n_devices`, 8e): HOST buffers, one context per device in ctxs[0..n_ctx-1].  Row i is
+ * evaluated by ctxs[i mod n_ctx] (interleaved sharding; one host thread per context; no exchange between devices
+ * while they compute) and lands in row i of out / status / work.  The table does not depend on n_ctx.  This is the
+ * in-process form; the one-process-per-GPU form with an RCCL gather is rimphony_amd/sharding.py + bench.py. */
+int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx, int dist_kind, size_t n,
+                                 const double *s, const double *theta, const double *const *params,
+                                 uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work);
+
+/* Status histogram of a computed table: hist[slot * 8 + b] = rows whose status word of `slot` has bit b set
+ * (b = 0..6, the RIMPHONY_ST_* bits in order), hist[slot * 8 + 7] = rows with status 0.  Synchronous. */
+int rimphony_status_histogram_device(rimphony_ctx *ctx, size_t n, const int32_t *d_status, uint64_t hist[64], void *stream);
+
 /* full_calculation() alone: the normalisation constant of each point
  * (power_law.rs:93-103 etc.); NaN where the integral failed. */
 int rimphony_batch_norm_device(rimphony_ctx *ctx, int dist_kind, size_t n,
@@ -188,7 +232,8 @@ int rimphony_detmath_batch_device(rimphony_ctx *ctx, int op, size_t n, const dou
 /* The reference's own scalar FFI seam, leung-bessel/src/lib.rs:36-42
  *   extern { fn pkgw_bessel_j(n: c_double, x: c_double) -> c_double; fn pkgw_bessel_dj(...) -> c_double; }
  * exported under the same names so that crate can link this library in place of leung-bessel/src/bessel.c.
- * One single-element kernel launch per call on the current HIP device; failure -> NaN (the seam's convention). */
+ * HOST code (the host build of the device function): no HIP call, works without a GPU, reentrant; returns the
+ * same bits as rimphony_bessel_batch_device.  Failure -> NaN (the seam's convention, bessel.c:327-333, 382-388). */
 double pkgw_bessel_j(double n, double x);
 double pkgw_bessel_dj(double n, double x);
 

@@ -74,6 +74,12 @@ typedef struct {
     uint64_t max_outer_size;
     uint64_t bessel_calls;
     uint64_t norm_evals;
+    /* Faraday (Heyvaerts) sample mix, for the per-sample flop model of bench.py / DESIGN.md */
+    uint64_t hey_nr_samples;    /* non-resonant element samples                                   */
+    uint64_t hey_qr_i_samples;  /* quasi-resonant samples on the I_{+-1/3}, I_{+-2/3} branch (g < 10) */
+    uint64_t hey_qr_jy_samples; /* quasi-resonant samples on the J_nu / Y_nu branch (g >= 10)        */
+    uint64_t hey_series_terms;  /* terms summed by the ascending Bessel series                      */
+    uint64_t hey_series_calls;
 } rimo_counters;
 
 typedef double (*rimo_fn)(double x, void *ctx);

@@ -61,15 +61,20 @@ double rimo_gamma_real(double z)
 #endif
 }
 
+/* work counters of the calling thread's Heyvaerts evaluation (null outside one) */
+static __thread rimo_counters *t_ctr = 0;
+
 /* sum_k (sign q)^k / (k! (nu+1)_k),  q = (x/2)^2 */
 static double ascending_series(double nu, double q, double sign)
 {
     double term = 1., sum = 1.;
-    for (int k = 1; k <= 500; k++) {
+    int k;
+    for (k = 1; k <= 500; k++) {
         term = term * (sign * q / (k * (k + nu)));
         sum = sum + term;
         if (m_fabs(term) < 1e-17 * m_fabs(sum)) break;
     }
+    if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) (k <= 500 ? k : 500); t_ctr->hey_series_calls += 1; }
     return sum;
 }
 
@@ -228,7 +233,7 @@ static double nr_inner_cb(double sigma, void *ctx)
 {
     hey_state *st = (hey_state *) ctx;
     fill_coord_vars(st, sigma, st->fixed);
-    if (st->c) st->c->integrand_evals++;
+    if (st->c) { st->c->integrand_evals++; st->c->hey_nr_samples++; }
     return st->stokes == RIMO_STOKES_Q ? h_nr_element(st) : f_nr_element(st);
 }
 
@@ -236,7 +241,11 @@ static double qr_inner_cb(double pomega, void *ctx)
 {
     hey_state *st = (hey_state *) ctx;
     fill_coord_vars(st, st->fixed, pomega);
-    if (st->c) st->c->integrand_evals++;
+    if (st->c) {
+        st->c->integrand_evals++;
+        const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
+        if (g < G_APPROXIMATION_CUTOFF) st->c->hey_qr_i_samples++; else st->c->hey_qr_jy_samples++;
+    }
     return st->stokes == RIMO_STOKES_Q ? h_qr_element(st) : f_qr_element(st);
 }
 
@@ -316,6 +325,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
     st.ows = rimo_workspace_alloc(4096);
     st.iws = rimo_workspace_alloc(4096);
     st.c = c;
+    t_ctr = c;
 
     double pomega_left = -3. * st.sigma0;
     double pomega_right = 3. * st.sigma0;
@@ -384,6 +394,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
     }
 
 done:
+    t_ctr = 0;
     rimo_workspace_free(st.ows);
     rimo_workspace_free(st.iws);
     return result;

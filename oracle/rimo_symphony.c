@@ -385,6 +385,11 @@ static void counters_add(rimo_counters *a, const rimo_counters *b)
     if (b->max_outer_size > a->max_outer_size) a->max_outer_size = b->max_outer_size;
     a->bessel_calls += b->bessel_calls;
     a->norm_evals += b->norm_evals;
+    a->hey_nr_samples += b->hey_nr_samples;
+    a->hey_qr_i_samples += b->hey_qr_i_samples;
+    a->hey_qr_jy_samples += b->hey_qr_jy_samples;
+    a->hey_series_terms += b->hey_series_terms;
+    a->hey_series_calls += b->hey_series_calls;
 }
 
 int rimo_batch(int kind, size_t n, const double *s, const double *theta, const double *const *params,

@@ -22,6 +22,9 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 HIPCC_FLAGS = [
     "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
+    # host side of the translation units (the pkgw_bessel_j / pkgw_bessel_dj seam is the HOST build of
+    # dev_bessel.h): inline fma instead of calls into libm, as the oracle's Makefile does
+    "-Xarch_host", "-mfma",
 ]
 
 

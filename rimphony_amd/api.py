@@ -99,31 +99,78 @@ class Context:
         return t.to(self._dev()).contiguous()
 
     # -- batched compute() -------------------------------------------------------
-    def compute_batch_device(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False):
+    def _check_input(self, name, t, n):
+        """The C ABI takes raw device pointers and cannot see what they point to: refuse anything but a contiguous
+        float64 tensor of n elements on this context's GPU (a strided view, a float32 tensor, a tensor on another
+        device or a length-1 'broadcast' parameter would be read as garbage or out of bounds)."""
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s: expected a torch.Tensor, got %s" % (name, type(t).__name__))
+        if not t.is_cuda or t.device != self._dev():
+            raise ValueError("%s: tensor is on %s, this context computes on %s" % (name, t.device, self._dev()))
+        if t.dtype != torch.float64:
+            raise TypeError("%s: dtype %s, expected float64" % (name, t.dtype))
+        if t.numel() != n:
+            raise ValueError("%s: %d elements, expected %d (one per parameter point; scalars are not broadcast)"
+                             % (name, t.numel(), n))
+        if not t.is_contiguous():
+            raise ValueError("%s: not contiguous (pass t.contiguous())" % name)
+
+    def compute_batch_device(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False):
         """s, theta: CUDA float64 tensors [n]; params: list of CUDA float64 tensors [n].
-        Returns (out [n, 8] CUDA tensor, status [n, 8] int32 CUDA tensor or None).
-        Asynchronous on the current stream."""
+        Returns (out [n, 8] CUDA tensor, status [n, 8] int32 CUDA tensor or None) -- and, with want_work, a third
+        element: [n, 8] int64 integrand samples spent per coefficient.  Asynchronous on the current stream."""
+        if kind not in NPARAMS:
+            raise ValueError("unknown distribution kind %r" % (kind,))
+        if len(params) != NPARAMS[kind]:
+            raise ValueError("distribution kind %d takes %d parameter arrays, got %d" % (kind, NPARAMS[kind], len(params)))
+        if not isinstance(s, torch.Tensor):
+            raise TypeError("s: expected a torch.Tensor, got %s" % type(s).__name__)
         n = s.numel()
-        assert len(params) == NPARAMS[kind]
+        self._check_input("s", s, n)
+        self._check_input("theta", theta, n)
+        for k, p in enumerate(params):
+            self._check_input("params[%d]" % k, p, n)
         out = torch.empty((n, 8), dtype=torch.float64, device=self._dev())
         status = torch.empty((n, 8), dtype=torch.int32, device=self._dev()) if want_status else None
+        work = torch.empty((n, 8), dtype=torch.int64, device=self._dev()) if want_work else None
         pp = (ctypes.c_void_p * len(params))(*[ctypes.c_void_p(p.data_ptr()) for p in params])
-        capi.check(self.lib.rimphony_batch_compute_device(
+        capi.check(self.lib.rimphony_batch_compute_device_ex(
             self.handle, kind, n, ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(theta.data_ptr()), pp,
-            coeff_mask, ctypes.c_void_p(out.data_ptr()),
-            ctypes.c_void_p(status.data_ptr()) if want_status else None, self._stream()),
-            "rimphony_batch_compute_device")
+            coeff_mask, 0, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(status.data_ptr()) if want_status else None,
+            ctypes.c_void_p(work.data_ptr()) if want_work else None, self._stream()),
+            "rimphony_batch_compute_device_ex")
+        if want_work:
+            return out, status, work
         return out, status
 
-    def compute_batch(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False):
+    def compute_batch(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False):
         """Host arrays in, numpy arrays out (synchronous)."""
         ds, dth = self._as_dev(s), self._as_dev(theta)
         dp = [self._as_dev(p) for p in params]
-        out, st = self.compute_batch_device(kind, ds, dth, dp, coeff_mask, want_status)
+        res = self.compute_batch_device(kind, ds, dth, dp, coeff_mask, want_status, want_work)
         torch.cuda.synchronize(self._dev())
+        ret = [res[0].cpu().numpy()]
         if want_status:
-            return out.cpu().numpy(), st.cpu().numpy()
-        return out.cpu().numpy()
+            ret.append(res[1].cpu().numpy())
+        if want_work:
+            ret.append(res[2].cpu().numpy())
+        return ret[0] if len(ret) == 1 else tuple(ret)
+
+    def shared_mode(self):
+        """False when this context owns its GPU (full persistent grids, cooperative tail); True when another context
+        or process had the device first (rimphony_ctx_create in include/rimphony_hip.h)."""
+        return bool(self.lib.rimphony_ctx_shared_mode(self.handle))
+
+    def status_histogram(self, status):
+        """status: the [n, 8] int32 CUDA tensor of a batch call -> numpy [8 slots, 8] counts: columns 0..6 = rows
+        with RIMPHONY_ST_* bit b set, column 7 = rows with status 0."""
+        if not (isinstance(status, torch.Tensor) and status.is_cuda and status.dtype == torch.int32 and status.is_contiguous()):
+            raise TypeError("status: expected a contiguous int32 CUDA tensor")
+        hist = (ctypes.c_uint64 * 64)()
+        capi.check(self.lib.rimphony_status_histogram_device(self.handle, status.numel() // 8, ctypes.c_void_p(status.data_ptr()),
+                                                              hist, self._stream()), "rimphony_status_histogram_device")
+        return np.array(list(hist), dtype=np.int64).reshape(8, 8)
 
     DETMATH_OPS = {"exp": 0, "log": 1, "log10": 2, "pow": 3, "sqrt": 4, "log10_region": 5, "lgamma": 6, "sin": 7, "cos": 8,
                    "div_by": 9}
@@ -279,6 +326,33 @@ class Context:
             "rimphony_qag_selftest_device")
         torch.cuda.synchronize(self._dev())
         return res.cpu().numpy(), err.cpu().numpy(), qst.cpu().numpy(), size.cpu().numpy()
+
+
+def compute_batch_multi(ctxs, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False):
+    """The in-process multi-GPU batch (rimphony_batch_compute_multi): host arrays in, row i evaluated by
+    ctxs[i mod len(ctxs)], numpy [n, 8] out (+ status, + work).  The table does not depend on len(ctxs)."""
+    lib = capi.load()
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    params = [np.ascontiguousarray(p, dtype=np.float64) for p in params]
+    n = s.size
+    if theta.size != n or any(p.size != n for p in params):
+        raise ValueError("s, theta and every parameter array must have one element per point")
+    if len(params) != NPARAMS[kind]:
+        raise ValueError("distribution kind %d takes %d parameter arrays" % (kind, NPARAMS[kind]))
+    dp = ctypes.POINTER(ctypes.c_double)
+    out = np.empty((n, 8), dtype=np.float64)
+    status = np.empty((n, 8), dtype=np.int32) if want_status else None
+    work = np.empty((n, 8), dtype=np.uint64) if want_work else None
+    handles = (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    pp = (dp * len(params))(*[p.ctypes.data_as(dp) for p in params])
+    capi.check(lib.rimphony_batch_compute_multi(
+        handles, len(ctxs), kind, n, s.ctypes.data_as(dp), theta.ctypes.data_as(dp), pp, coeff_mask, 0,
+        out.ctypes.data_as(dp),
+        status.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if want_status else None,
+        work.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)) if want_work else None), "rimphony_batch_compute_multi")
+    ret = [out] + ([status] if want_status else []) + ([work] if want_work else [])
+    return ret[0] if len(ret) == 1 else tuple(ret)
 
 
 _default_ctx = None

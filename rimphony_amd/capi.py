@@ -15,6 +15,8 @@ SYMBOLS = [
     "rimphony_version", "rimphony_last_work", "rimphony_last_symphony_ms", "rimphony_last_faraday_ms", "rimphony_debug_heartbeat", "rimphony_debug_counters", "rimphony_batch_compute_device", "rimphony_batch_compute",
     "rimphony_batch_norm_device", "rimphony_bessel_batch_device", "rimphony_gamma_integrand_batch_device",
     "rimphony_gamma_integral_batch_device", "rimphony_n_integral_batch_device", "rimphony_gamma_contribution_batch_device", "rimphony_calc_f_batch_device", "rimphony_calc_f_batch", "rimphony_qag_selftest_device", "rimphony_highfreq_batch_device", "rimphony_highfreq_batch", "rimphony_detmath_batch_device", "pkgw_bessel_j", "pkgw_bessel_dj",
+    "rimphony_ctx_shared_mode", "rimphony_last_error", "rimphony_batch_compute_device_ex", "rimphony_batch_compute_ex",
+    "rimphony_batch_compute_multi", "rimphony_status_histogram_device",
 ]
 
 
@@ -100,11 +102,28 @@ def load():
     lib.rimphony_qag_selftest_device.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_double, c_double, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p]
+    lib.rimphony_ctx_shared_mode.restype = c_int
+    lib.rimphony_ctx_shared_mode.argtypes = [c_void_p]
+    lib.rimphony_last_error.restype = c_char_p
+    lib.rimphony_last_error.argtypes = []
+    lib.rimphony_batch_compute_device_ex.restype = c_int
+    lib.rimphony_batch_compute_device_ex.argtypes = [c_void_p, c_int, c_size_t, c_void_p, c_void_p, POINTER(c_void_p),
+                                                     c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_batch_compute_ex.restype = c_int
+    lib.rimphony_batch_compute_ex.argtypes = [c_void_p, c_int, c_size_t, dp, dp, POINTER(dp), c_uint32, c_int, dp,
+                                              POINTER(c_int32), POINTER(c_uint64)]
+    lib.rimphony_batch_compute_multi.restype = c_int
+    lib.rimphony_batch_compute_multi.argtypes = [POINTER(c_void_p), c_int, c_int, c_size_t, dp, dp, POINTER(dp), c_uint32,
+                                                 c_int, dp, POINTER(c_int32), POINTER(c_uint64)]
+    lib.rimphony_status_histogram_device.restype = c_int
+    lib.rimphony_status_histogram_device.argtypes = [c_void_p, c_size_t, c_void_p, POINTER(c_uint64), c_void_p]
     _lib = lib
     return lib
 
 
 def check(rc, what):
     if rc != 0:
-        msg = load().rimphony_strerror(rc).decode()
-        raise RimphonyError("%s failed: %s (code %d)" % (what, msg, rc))
+        lib = load()
+        msg = lib.rimphony_strerror(rc).decode()
+        detail = lib.rimphony_last_error().decode()
+        raise RimphonyError("%s failed: %s (code %d)%s" % (what, msg, rc, " -- " + detail if detail else ""))

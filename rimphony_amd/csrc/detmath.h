@@ -28,18 +28,32 @@
 #define RIM_FN static inline
 #endif
 
-/* Region timers of the diagnostic build (-DRIM_PROF, tools/region_profile.py); no-ops otherwise. */
+/* Region timers of the diagnostic build (-DRIM_PROF, tools/region_profile.py); no-ops otherwise.
+ * -DRIM_PROF -DRIM_PROF_COUNTS turns the timers off and counts instead how often a wave enters the places marked
+ * RIM_HIT(idx) (counted by the first ACTIVE lane, so a branch that any lane takes counts once per wave):
+ * execution frequencies to weight the static instruction counts of tools/isa_mix.py with. */
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
-extern __shared__ unsigned long long rim_prof_lds[];      /* 16 words of dynamic LDS per workgroup */
+extern __shared__ unsigned long long rim_prof_lds[];      /* 32 words of dynamic LDS per workgroup */
+#if defined(RIM_PROF_COUNTS)
+#define RIM_PROF_T(t)
+#define RIM_PROF_ADD(idx, t)
+#define RIM_PROF_COUNT(idx, v)
+#define RIM_HIT(idx) do { const unsigned long long rim_ex_ = __builtin_amdgcn_read_exec(); \
+    if (__builtin_amdgcn_mbcnt_hi((unsigned) (rim_ex_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) rim_ex_, 0u)) == 0u) \
+        __hip_atomic_fetch_add(&rim_prof_lds[idx], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#else
 #define RIM_PROF_T(t) const unsigned long long t = __builtin_readcyclecounter()
 #define RIM_PROF_ADD(idx, t) do { if ((threadIdx.x & 63) == 0) \
     __hip_atomic_fetch_add(&rim_prof_lds[idx], __builtin_readcyclecounter() - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #define RIM_PROF_COUNT(idx, v) do { if ((threadIdx.x & 63) == 0) \
     __hip_atomic_fetch_add(&rim_prof_lds[idx], (unsigned long long) (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#define RIM_HIT(idx)
+#endif
 #else
 #define RIM_PROF_T(t)
 #define RIM_PROF_ADD(idx, t)
 #define RIM_PROF_COUNT(idx, v)
+#define RIM_HIT(idx)
 #endif
 
 #define RIM_NAN (__builtin_nan(""))

@@ -44,6 +44,7 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
     if (f_factor == 0.) return 0.;
     const double a = rim_fabs(f_exp);
     if (a < 1e-3) {
+        RIM_HIT(10);
         const double x = f_exp;
         double q = 8 + x;
         q = rim_fma_k(q, x, 56.);
@@ -57,13 +58,15 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
     // exp(-760) and exp(log|f| - 760) are exactly 0 for |f| < 1e6 (rim_exp returns 0 below -745.2), so
     // both arms of the large-exponent branch below give f_factor * 0: skip its log and exp.  Most
     // samples of a gamma-integral lie far out on the exponentially small side of J_n.
-    if (f_exp < -760. && rim_fabs(f_factor) < 1e6) return f_factor * 0.;
+    if (f_exp < -760. && rim_fabs(f_factor) < 1e6) { RIM_HIT(11); return f_factor * 0.; }
     if (a > 690.) {
+        RIM_HIT(12);
         const double sign_f = (f_factor < 0) ? -1. : 1.;
         const double log_f = rim_log(rim_fabs(f_factor));
         if (log_f * f_exp < 0.) return sign_f * rim_exp(log_f + f_exp);
         return f_factor * rim_exp(f_exp);
     }
+    RIM_HIT(13);
     return f_factor * rim_exp_bounded(f_exp);      // 1e-3 <= |f_exp| <= 690 here (or NaN, which stays NaN)
 }
 
@@ -123,6 +126,7 @@ RIM_DEV LeungOrder leung_order(double n)
 // (Chishtie et al. 2005, as tabulated in bessel.c:108-118).
 RIM_DEV double meissel_first(const LeungOrder &o, double x)
 {
+    RIM_HIT(6);
     const double n = o.n;
     const double z = rim_div_by(x, n, o.ninv);
     const double eps = rim_div_by(n - x, n, o.ninv);
@@ -182,6 +186,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
 
     double exp_val;
     if (eps < 1e-4 && o.big_n) {
+        RIM_HIT(7);
         double q = rim_fma_k(0.139204065e9, eps, 0.160692840e9);
         q = rim_fma_k(q, eps, 0.190139040e9);
         q = rim_fma_k(q, eps, 0.233192960e9);
@@ -193,6 +198,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     } else {
         double invZp1;
         if (Z < 1.e-3) {
+            RIM_HIT(8);
             double q = 1 - Z;
             q = rim_fma_k(q, Z, -1.);
             q = rim_fma_k(q, Z, 1.);
@@ -204,6 +210,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
         } else {
             invZp1 = rim_div_moderate(1., 1. + Z);
         }
+        RIM_HIT(9);
         RIM_PROF_T(t_ml);
         // x * invZp1 is a positive normal number except for x = +0 or a subnormal x; there rim_log_normal gives
         // about -709 instead of -inf / -720, and either way n >= 30 makes exp_val < -2e4: exp_factor returns
@@ -290,6 +297,7 @@ RIM_DEV double debye_eps(double n, double x)
 RIM_DEV void debye_eps_pair(double n0, double n1, double x, double *r0, double *r1)
 {
     if (x > 1.e55) { *r0 = RIM_NAN; *r1 = RIM_NAN; return; }
+    RIM_HIT(5);
 
     const double ez0 = x - n0, ez1 = x - n1;
     RIM_PROF_T(t_dp);
@@ -406,15 +414,18 @@ RIM_DEV LeungSel leung_select(const LeungOrder &o, double x)
         if (r < o.r_lo_dn) s.need_debye = true;
         else if (r > o.r_hi_up) s.need_meissel = true;
         else {
+            RIM_HIT(4);
             const double eta = rim_log10_region(r);
             if (eta < o.thr_lo) s.need_debye = true;
             else if (eta > o.thr_hi) s.need_meissel = true;
             else {
+                RIM_HIT(18);
                 s.need_debye = true; s.need_meissel = true; s.blend = true;
                 s.pos = (eta - o.thr_lo) / (0.295966 - 0.174857);
             }
         }
     } else {
+        RIM_HIT(17);
         const double r = (x - n) / x;
         if (r < o.rp_dn) s.need_debye = true;
         else if (r > o.rp_up) s.unsupported = true;      // Meissel "second" region: off the hot path

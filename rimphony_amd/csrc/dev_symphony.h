@@ -68,6 +68,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
 {
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
+        RIM_HIT(19);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
         return d.norm * rim_pow_normal(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
     } else if (KIND == DIST_THERMAL_JUETTNER) {
@@ -92,6 +93,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
 {
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) { dfdg = 0.; dfdcx = 0.; return; }
+        RIM_HIT(20);
         const double p_plus_1 = d.par[0] + 1.;
         const double g2_minus_1 = gamma * gamma - 1.;
         dfdg = -d.norm * rim_pow_normal(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
@@ -205,6 +207,7 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
             jv0 = RIM_NAN; jv1 = RIM_NAN;
         } else {
             double a, b;
+            RIM_HIT(16);
             RIM_PROF_T(t_mil);
             jn_int_pair(n_int, z, &a, &b);
             RIM_PROF_ADD(8, t_mil);
@@ -239,8 +242,10 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
 
     double gamma_sin_xi;
     if (beta < 0.1) {
+        RIM_HIT(14);
         gamma_sin_xi = gamma * sin_xi;
     } else {
+        RIM_HIT(15);
         const double bc = beta * cos_th;
         const double beta2_costh2 = bc * bc;
         const double s_on_r = rim_div_moderate(2. * n, s * (beta2_costh2 - 1.));
@@ -266,9 +271,11 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
 
     double f_term;
     if (pt.coeff == COEFF_EMISSION) {
+        RIM_HIT(24);
         f_term = calc_f<KIND>(d, gamma, cos_xi);
     } else {
         double dfdg, dfdcx;
+        RIM_HIT(25);
         calc_f_derivatives<KIND>(d, gamma, cos_xi, dfdg, dfdcx);
         const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
         f_term = dfdg + dfdcx_factor * dfdcx;

@@ -16,9 +16,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <mutex>
+#include <thread>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "../../include/rimphony_hip.h"
 #include "symphony_wave.h"
 #include "heyvaerts_wave.h"
@@ -147,6 +153,9 @@ struct SymArgs {
     const double *series_tab;       // Heyvaerts: divisors of the fixed-order Bessel series and their reciprocals
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
+    unsigned long long *work;       // optional [n][8]: integrand samples spent on each coefficient (null: not counted)
+    unsigned long long idle_ticks;  // wall_clock64 ticks after which a helper that has found nothing leaves (2 s)
+    unsigned long long owner_ticks; // ... after which an owner stops waiting for helpers and recomputes its batch (120 s)
 };
 
 #if defined(RIM_PROF)
@@ -401,6 +410,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     size_t own_i = 0;
     int own_slot = 0;
     bool have_task = false, helper = false;
+    bool board_dead = false;               // this wave once gave up waiting for helpers: it never publishes again (below)
     unsigned last_hint = 0;                // lane 0: the hint whose batch this wave has already seen exhausted
 
     __builtin_amdgcn_s_setprio(3);
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
             const int cnt = __builtin_popcountll(mask);
-            shared = idle != 0 && cnt >= 2;
+            shared = idle != 0 && cnt >= 2 && !board_dead;
             if (shared) {
                 seq += 1;
                 src_seq = seq;
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 // sizes it so that it is), the waves waiting for a slot get one instead of being waited for.
                 const unsigned long long now = wall_clock64();
                 if (idle_since == 0) idle_since = now;
-                else if (now - idle_since > 200000000ull) {
+                else if (now - idle_since > a.idle_ticks) {
                     if (counted_idle && lane == 0)
                         __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -581,6 +591,11 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         bool ctx_loaded = !helper;
         unsigned long long local_mask = mask;
         int got = 0;
+        size_t work_i = own_i;             // the task the evaluated requests belong to (per-slot work counters)
+        int work_slot = own_slot;
+        bool redo;
+        do {
+        redo = false;
         for (;;) {
             int k;
             if (shared) {
@@ -600,6 +615,8 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     const size_t hi = (size_t) bcast_u64(bget(&src->point));
                     const int hs = __builtin_amdgcn_readfirstlane(bget(&src->slot));
                     P::load(a, hi, hs, cx, norm);
+                    work_i = hi;
+                    work_slot = hs;
                     ctx_loaded = true;
                     if (counted_idle) {
                         if (lane == 0) __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -633,7 +650,11 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             double val, val2;
             COOP_DIAG(const unsigned long long e0 = wall_clock64();)
             RIM_PROF_T(t_req);
+            unsigned long long samples_before = 0;
+            if (a.work && lane == 0) samples_before = s_qpark.ctr.samples;
             P::eval2(cx, g, inner, &s_qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
+            if (a.work && lane == 0)
+                atomicAdd(a.work + work_i * 8 + (size_t) work_slot, s_qpark.ctr.samples - samples_before);
             RIM_PROF_ADD(9, t_req);
             COOP_DIAG(eval_ticks += wall_clock64() - e0;)
             if (shared) {
@@ -649,22 +670,9 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 batch_status |= st | st2;
             }
         }
-        if (helper) {
-            if (got == 0) {
-                // every request of that batch was already taken: back off before looking again
-                // (last_hint is not set here: the claim word is re-read on the next poll, and that
-                // poll files the hint away once the batch shows no open request)
-                COOP_DIAG(n_empty_claims += 1;)
-                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
-                if (backoff < 16) backoff *= 2;
-            } else {
-                if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                counted_idle = true;
-            }
-            continue;
-        }
+        if (helper) break;
 
-        // ---------- owner: collect a shared batch, then the continuation ----------
+        // ---------- owner: collect a shared batch ----------
         if (shared) {
             const unsigned want = (unsigned) __builtin_popcountll(mask);
             const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
@@ -679,16 +687,43 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     COOP_DIAG(const unsigned long long w = wall_clock64() - t0; wait_ticks += w; if (w > max_wait) max_wait = w;)
                     break;
                 }
-                if (wall_clock64() - t0 > 12000000000ull) break;      // 120 s at 100 MHz: give up, flag the task
+                if (wall_clock64() - t0 > a.owner_ticks) break;
                 __builtin_amdgcn_s_sleep(32);
             }
-            int stl = 0;
-            if ((mask >> lane) & 1ull) { gval = rim_frombits(bget(&my->res[rank])); stl = bget(&my->res_status[rank]); }
-            if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
-            if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
-            if (!complete) { batch_status |= ST_CHUNK_CAP; gval = RIM_NAN; }
             if (lane == 0)
                 __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (complete) {
+                int stl = 0;
+                if ((mask >> lane) & 1ull) { gval = rim_frombits(bget(&my->res[rank])); stl = bget(&my->res_status[rank]); }
+                if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
+                if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
+            } else {
+                // A claimed request has not come back within the bound (a helper wave that is not running: the GPU is
+                // shared, or part of the grid is not resident).  The value of a request does not depend on who
+                // evaluates it, so the owner closes the batch and evaluates ALL of it itself -- same bits, only later --
+                // and never publishes again: whatever a late helper still writes to this slot is never read.
+                board_dead = true;
+                shared = false;
+                local_mask = mask;
+                batch_status = 0;
+                gval = 0.;
+                redo = true;
+            }
+        }
+        } while (redo);
+        if (helper) {
+            if (got == 0) {
+                // every request of that batch was already taken: back off before looking again
+                // (last_hint is not set here: the claim word is re-read on the next poll, and that
+                // poll files the hint away once the batch shows no open request)
+                COOP_DIAG(n_empty_claims += 1;)
+                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
+                if (backoff < 16) backoff *= 2;
+            } else {
+                if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counted_idle = true;
+            }
+            continue;
         }
         __syncthreads();
         {
@@ -925,7 +960,28 @@ struct rimphony_ctx {
     unsigned long long *hb_host;
     unsigned long long *hb_dev;
     unsigned long long hb_task;
+    // resident workgroups per CU of coop_kernel<P>, by problem (0 Symphony, 1 Heyvaerts) and distribution kind:
+    // queried once per context (= per device) and instantiation
+    int resident[2][4];
+    // 0: this context has the GPU to itself (it holds the device's lock file); 1: another context or process had
+    // the device first -- smaller persistent grids, no cooperative tail (see rimphony_ctx_create)
+    int shared_mode;
+    int lock_fd;
+    unsigned long long ticks_per_s;  // wall_clock64 rate of the device
+    // successive batch calls of a context share its workspace: each call's stream waits for the previous call's
+    // work (ev_batch), and the calls themselves are serialised by mu
+    hipEvent_t ev_batch;
+    int ev_batch_valid;
+    std::mutex *mu;
 };
+
+// ---- last error (thread-local text; the codes are in rimphony_hip.h) ---------------------------
+static thread_local char t_last_error[256] = "";
+void rim_set_last_error(const char *what, const char *detail)
+{
+    snprintf(t_last_error, sizeof t_last_error, "%s: %s", what ? what : "?", detail ? detail : "?");
+}
+extern "C" const char *rimphony_last_error(void) { return t_last_error; }
 
 static const int NPARAMS[4] = { 4, 1, 5, 4 };
 
@@ -943,11 +999,57 @@ extern "C" const char *rimphony_strerror(int code)
     case RIMPHONY_EHIP: return "HIP runtime error";
     case RIMPHONY_ENOMEM: return "out of memory";
     case RIMPHONY_ENODEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case RIMPHONY_EBUSY: return "the device is in use by another rimphony context (RIMPHONY_EXCLUSIVE=1)";
+    case RIMPHONY_ENOTSUP: return "not supported";
     default: return "unknown error";
     }
 }
 
-extern "C" const char *rimphony_version(void) { return "rimphony_hip 0.1 (gfx950)"; }
+extern "C" const char *rimphony_version(void) { return "rimphony_hip 0.2 (gfx950)"; }
+
+// One context per GPU is the supported configuration: the persistent grids of the two coefficient kernels fill the
+// device and their idle waves help the busy ones (cooperative tail), which only works while every wave of the grid is
+// resident.  Whether somebody else is on the device cannot be asked of the runtime, so contexts announce themselves:
+// the first one on a device (any process) takes an exclusive flock on /dev/shm/rimphony_hip.<pci bus id>.lock and
+// keeps it for its lifetime; a context that finds the lock taken runs in SHARED mode -- quarter-size grids, no
+// cooperative tail, hence no wave ever waits for another -- or, with RIMPHONY_EXCLUSIVE=1, is refused (RIMPHONY_EBUSY).
+static int take_device_lock(int device, int *fd_out)
+{
+    *fd_out = -1;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
+    for (char *q = bus; *q; q++) if (*q == ':' || *q == '/') *q = '_';
+    char path[160];
+    snprintf(path, sizeof path, "/dev/shm/rimphony_hip.%s.lock", bus);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) return 0;                       // cannot tell: assume the device is ours
+    (void) fchmod(fd, 0666);
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { *fd_out = fd; return 0; }
+    close(fd);
+    return 1;                                   // somebody else holds it
+}
+
+static void ctx_free(rimphony_ctx *c)
+{
+    if (c->d_queue) (void) hipFree(c->d_queue);
+    if (c->d_series) (void) hipFree(c->d_series);
+    if (c->d_norm) (void) hipFree(c->d_norm);
+    if (c->d_perm) (void) hipFree(c->d_perm);
+    if (c->d_spill) (void) hipFree(c->d_spill);
+    if (c->d_board) (void) hipFree(c->d_board);
+    if (c->d_in) (void) hipFree(c->d_in);
+    if (c->d_out) (void) hipFree(c->d_out);
+    if (c->d_status) (void) hipFree(c->d_status);
+    if (c->hb_host) (void) hipHostFree(c->hb_host);
+    if (c->ev_start) (void) hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void) hipEventDestroy(c->ev_stop);
+    if (c->ev_fstart) (void) hipEventDestroy(c->ev_fstart);
+    if (c->ev_fstop) (void) hipEventDestroy(c->ev_fstop);
+    if (c->ev_batch) (void) hipEventDestroy(c->ev_batch);
+    if (c->lock_fd >= 0) close(c->lock_fd);     // releases the flock
+    delete c->mu;
+    delete c;
+}
 
 extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
 {
@@ -963,27 +1065,32 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     if (!c) return RIMPHONY_ENOMEM;
     memset(c, 0, sizeof *c);
     c->device = device;
+    c->lock_fd = -1;
+    c->mu = new (std::nothrow) std::mutex();
+    if (!c->mu) { delete c; return RIMPHONY_ENOMEM; }
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
+    c->shared_mode = take_device_lock(device, &c->lock_fd);
+    if (c->shared_mode) {
+        const char *e = getenv("RIMPHONY_EXCLUSIVE");
+        if (e && e[0] == '1') { ctx_free(c); return RIMPHONY_EBUSY; }
+        c->no_assist = 1;
+    }
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&c->d_queue, 16 * sizeof(unsigned long long)) != hipSuccess) { delete c; return RIMPHONY_ENOMEM; }
+    {   // rate of wall_clock64() (s_memrealtime): 100 MHz on gfx950, asked rather than assumed
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
+        c->ticks_per_s = (unsigned long long) khz * 1000ull;
+    }
+    if (hipMalloc(&c->d_queue, 16 * sizeof(unsigned long long)) != hipSuccess) { ctx_free(c); return RIMPHONY_ENOMEM; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
-        hipEventCreate(&c->ev_fstart) != hipSuccess || hipEventCreate(&c->ev_fstop) != hipSuccess) {
-        (void) hipFree(c->d_queue);
-        delete c;
+        hipEventCreate(&c->ev_fstart) != hipSuccess || hipEventCreate(&c->ev_fstop) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_batch, hipEventDisableTiming) != hipSuccess) {
+        ctx_free(c);
         return RIMPHONY_EHIP;
     }
-    if (hipMalloc(&c->d_series, 4 * RIM_SERIES_ROW * sizeof(double)) != hipSuccess) {
-        (void) hipFree(c->d_queue);
-        delete c;
-        return RIMPHONY_ENOMEM;
-    }
+    if (hipMalloc(&c->d_series, 4 * RIM_SERIES_ROW * sizeof(double)) != hipSuccess) { ctx_free(c); return RIMPHONY_ENOMEM; }
     hipLaunchKernelGGL(series_table_kernel, dim3((4 * (RIM_SERIES_TERMS + 1) + 255) / 256), dim3(256), 0, (hipStream_t) 0, c->d_series);
-    if (hipDeviceSynchronize() != hipSuccess) {
-        (void) hipFree(c->d_series);
-        (void) hipFree(c->d_queue);
-        delete c;
-        return RIMPHONY_EHIP;
-    }
+    if (hipDeviceSynchronize() != hipSuccess) { ctx_free(c); return RIMPHONY_EHIP; }
     *out = c;
     return RIMPHONY_OK;
 }
@@ -992,22 +1099,11 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
 {
     if (!c) return;
     (void) hipSetDevice(c->device);
-    if (c->d_queue) (void) hipFree(c->d_queue);
-    if (c->d_series) (void) hipFree(c->d_series);
-    if (c->d_norm) (void) hipFree(c->d_norm);
-    if (c->d_perm) (void) hipFree(c->d_perm);
-    if (c->d_spill) (void) hipFree(c->d_spill);
-    if (c->d_board) (void) hipFree(c->d_board);
-    if (c->d_in) (void) hipFree(c->d_in);
-    if (c->d_out) (void) hipFree(c->d_out);
-    if (c->d_status) (void) hipFree(c->d_status);
-    if (c->hb_host) (void) hipHostFree(c->hb_host);
-    (void) hipEventDestroy(c->ev_start);
-    (void) hipEventDestroy(c->ev_stop);
-    (void) hipEventDestroy(c->ev_fstart);
-    (void) hipEventDestroy(c->ev_fstop);
-    delete c;
+    (void) hipDeviceSynchronize();
+    ctx_free(c);
 }
+
+extern "C" int rimphony_ctx_shared_mode(const rimphony_ctx *c) { return c ? c->shared_mode : RIMPHONY_EINVAL; }
 
 static int ensure_spill(rimphony_ctx *c, size_t waves)
 {
@@ -1028,8 +1124,13 @@ static int ensure_norm(rimphony_ctx *c, size_t n)
     c->d_norm = nullptr;
     c->d_perm = nullptr;
     c->norm_cap = 0;
-    if (hipMalloc(&c->d_norm, n * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
-    if (hipMalloc(&c->d_perm, (n + ORDER_BUCKETS) * sizeof(unsigned)) != hipSuccess) return RIMPHONY_ENOMEM;
+    if (hipMalloc(&c->d_norm, n * sizeof(double)) != hipSuccess) { c->d_norm = nullptr; return RIMPHONY_ENOMEM; }
+    if (hipMalloc(&c->d_perm, (n + ORDER_BUCKETS) * sizeof(unsigned)) != hipSuccess) {
+        (void) hipFree(c->d_norm);
+        c->d_norm = nullptr;
+        c->d_perm = nullptr;
+        return RIMPHONY_ENOMEM;
+    }
     c->norm_cap = n;
     return RIMPHONY_OK;
 }
@@ -1086,21 +1187,24 @@ extern "C" int rimphony_batch_norm_device(rimphony_ctx *c, int kind, size_t n, c
 }
 
 template <class P>
-static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int *resident)
 {
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) a.nslots;
     // more waves than tasks on small batches: the surplus waves start as helpers right away
-    const unsigned long long want_waves = ntasks > (1ull << 40) ? ntasks : ntasks * 64ull;
-    // Every wave of the grid must be resident: an idle wave waits for the waves that still own a task, so a wave
-    // that cannot start until another one exits would be waited for forever.  Ask the runtime how many of these
-    // workgroups a CU really holds (registers, LDS) instead of trusting the launch bounds.
-    static int resident_per_cu = 0;
-    if (resident_per_cu == 0) {
+    const unsigned long long want_waves = (ntasks > (1ull << 40) || c->no_assist) ? ntasks : ntasks * 64ull;
+    // Every wave of the grid should be resident: an idle wave waits for the waves that still own a task.  Ask the
+    // runtime how many of these workgroups a CU really holds (registers, LDS) instead of trusting the launch bounds;
+    // cached per context (= per device) and kernel instantiation.  The query knows nothing of other work on the
+    // device: should part of the grid not be resident after all, helpers leave after 2 s without work and an owner
+    // that waits in vain recomputes its batch itself (coop_kernel), so every wait ends and no result changes.
+    if (*resident == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, coop_kernel<P>, 64, RIM_DYN_LDS) != hipSuccess || nb < 1)
             nb = 4;       // conservative: one wave per SIMD
-        resident_per_cu = nb < 4 * (int) P::WAVES ? nb : 4 * (int) P::WAVES;
+        *resident = nb < 4 * (int) P::WAVES ? nb : 4 * (int) P::WAVES;
     }
+    int resident_per_cu = *resident;
+    if (c->shared_mode) resident_per_cu = resident_per_cu >= 8 ? resident_per_cu / 4 : 2;   // leave room for the other tenant
     const unsigned grid = persistent_grid(c, want_waves, resident_per_cu);
     int rc = ensure_spill(c, grid);
     if (rc) return rc;
@@ -1116,6 +1220,8 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     b.spill = c->d_spill;
     b.board = c->no_assist ? nullptr : c->d_board;
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
+    b.idle_ticks = 2ull * c->ticks_per_s;
+    b.owner_ticks = 120ull * c->ticks_per_s;
     // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);
@@ -1129,7 +1235,7 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
 template <int KIND>
 static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
-    const int rc = launch_coop<SymphonyProblem<KIND>>(c, a, st, c->ev_start, c->ev_stop);
+    const int rc = launch_coop<SymphonyProblem<KIND>>(c, a, st, c->ev_start, c->ev_stop, &c->resident[0][KIND]);
     if (rc == RIMPHONY_OK) c->ev_valid = 1;
     return rc;
 }
@@ -1137,8 +1243,34 @@ static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 template <int KIND>
 static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
-    const int rc = launch_coop<HeyvaertsProblem<KIND>>(c, a, st, c->ev_fstart, c->ev_fstop);
+    const int rc = launch_coop<HeyvaertsProblem<KIND>>(c, a, st, c->ev_fstart, c->ev_fstop, &c->resident[1][KIND]);
     if (rc == RIMPHONY_OK) c->evf_valid = 1;
+    return rc;
+}
+
+// The batch entry points share the context's workspace (task queue, norms, visiting order, spill regions, assist
+// board, timing events).  Calls on one context are therefore serialised on the host (c->mu) and ordered on the device:
+// a call's stream first waits for the event the previous call recorded after its last kernel, whatever stream that was.
+static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const double *d_s, const double *d_theta,
+                                const double *const *d_params, uint32_t coeff_mask, int precision,
+                                double *d_out, int32_t *d_status, uint64_t *d_work, hipStream_t st);
+
+extern "C" int rimphony_batch_compute_device_ex(rimphony_ctx *c, int kind, size_t n,
+                                                const double *d_s, const double *d_theta,
+                                                const double *const *d_params, uint32_t coeff_mask, int precision,
+                                                double *d_out, int32_t *d_status, uint64_t *d_work, void *stream)
+{
+    if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
+    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;      // F32_INTEGRAND: not built
+    if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
+    if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
+    std::lock_guard<std::mutex> lock(*c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    if (c->ev_batch_valid) HIP_TRY(hipStreamWaitEvent(st, c->ev_batch, 0));
+    const int rc = batch_compute_locked(c, kind, n, d_s, d_theta, d_params, coeff_mask, precision, d_out, d_status, d_work, st);
+    // also after a failure part-way: whatever was enqueued must finish before the workspace is reused
+    if (hipEventRecord(c->ev_batch, st) == hipSuccess) c->ev_batch_valid = 1;
     return rc;
 }
 
@@ -1147,14 +1279,18 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
                                              const double *const *d_params, uint32_t coeff_mask,
                                              double *d_out, int32_t *d_status, void *stream)
 {
-    if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
-    if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
-    if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
+    return rimphony_batch_compute_device_ex(c, kind, n, d_s, d_theta, d_params, coeff_mask, RIMPHONY_PRECISION_F64,
+                                            d_out, d_status, nullptr, stream);
+}
+
+static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const double *d_s, const double *d_theta,
+                                const double *const *d_params, uint32_t coeff_mask, int precision,
+                                double *d_out, int32_t *d_status, uint64_t *d_work, hipStream_t st)
+{
+    (void) precision;
     ParamPtrs pp;
     int rc = make_param_ptrs(kind, d_params, pp);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t) stream;
 
     rc = ensure_norm(c, n);
     if (rc) return rc;
@@ -1195,6 +1331,10 @@ extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n
     a.series_tab = c->d_series;
     a.heartbeat = c->hb_dev;
     a.hb_task = c->hb_task;
+    a.work = (unsigned long long *) d_work;
+    a.idle_ticks = 0;
+    a.owner_ticks = 0;
+    if (d_work) HIP_TRY(hipMemsetAsync(d_work, 0, n * 8 * sizeof(uint64_t), st));
     a.nslots = 0;
     uint32_t computed = 0;
     for (int k = 0; k < 6; k++)     // symphony slots: j/alpha x I,Q,V
@@ -1267,6 +1407,7 @@ extern "C" int rimphony_debug_counters(rimphony_ctx *c, uint64_t out[32])
     }
 #endif
     for (int k = 16; k < 32; k++) out[k] = 0;
+    if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));     // the launch may be on a non-blocking stream
     HIP_TRY(hipMemcpy(out, c->d_queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RIMPHONY_OK;
 }
@@ -1296,6 +1437,7 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[8];
+    if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));     // the launch may be on a non-blocking stream
     HIP_TRY(hipMemcpy(h, c->d_queue, sizeof h, hipMemcpyDeviceToHost));
     out->samples = h[1];
     out->passes = h[2];
@@ -1306,44 +1448,184 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
     return RIMPHONY_OK;
 }
 
+extern "C" int rimphony_batch_compute_ex(rimphony_ctx *c, int kind, size_t n,
+                                         const double *s, const double *theta, const double *const *params,
+                                         uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work)
+{
+    if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
+    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;
+    if (n == 0) return RIMPHONY_OK;
+    if (!s || !theta) return RIMPHONY_EINVAL;
+    const int np = NPARAMS[kind];
+    for (int k = 0; k < np; k++) if (!params[k]) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const double *dp[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    uint64_t *d_work = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(*c->mu);
+        if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));   // the staging buffers may still be in use
+        const size_t need_in = n * (size_t) (2 + np);
+        if (c->in_cap < need_in) {
+            if (c->d_in) (void) hipFree(c->d_in);
+            c->d_in = nullptr; c->in_cap = 0;
+            if (hipMalloc(&c->d_in, need_in * sizeof(double)) != hipSuccess) { c->d_in = nullptr; return RIMPHONY_ENOMEM; }
+            c->in_cap = need_in;
+        }
+        if (c->out_cap < n) {
+            if (c->d_out) (void) hipFree(c->d_out);
+            if (c->d_status) (void) hipFree(c->d_status);
+            c->d_out = nullptr; c->d_status = nullptr; c->out_cap = 0;
+            // status and the optional work counters share one allocation: [n][8] int32, then [n][8] uint64
+            if (hipMalloc(&c->d_out, n * 8 * sizeof(double)) != hipSuccess) { c->d_out = nullptr; return RIMPHONY_ENOMEM; }
+            if (hipMalloc(&c->d_status, n * 8 * (sizeof(int32_t) + sizeof(uint64_t))) != hipSuccess) {
+                (void) hipFree(c->d_out);
+                c->d_out = nullptr; c->d_status = nullptr;
+                return RIMPHONY_ENOMEM;
+            }
+            c->out_cap = n;
+        }
+        HIP_TRY(hipMemcpy(c->d_in, s, n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_in + n, theta, n * sizeof(double), hipMemcpyHostToDevice));
+        for (int k = 0; k < np; k++) {
+            HIP_TRY(hipMemcpy(c->d_in + (size_t) (2 + k) * n, params[k], n * sizeof(double), hipMemcpyHostToDevice));
+            dp[k] = c->d_in + (size_t) (2 + k) * n;
+        }
+        if (work) d_work = (uint64_t *) (c->d_status + c->out_cap * 8);
+    }
+    int rc = rimphony_batch_compute_device_ex(c, kind, n, c->d_in, c->d_in + n, dp, coeff_mask, precision, c->d_out,
+                                              c->d_status, d_work, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, c->d_out, n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, c->d_status, n * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (work) HIP_TRY(hipMemcpy(work, d_work, n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RIMPHONY_OK;
+}
+
 extern "C" int rimphony_batch_compute(rimphony_ctx *c, int kind, size_t n,
                                       const double *s, const double *theta, const double *const *params,
                                       uint32_t coeff_mask, double *out, int32_t *status)
 {
-    if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
+    return rimphony_batch_compute_ex(c, kind, n, s, theta, params, coeff_mask, RIMPHONY_PRECISION_F64, out, status, nullptr);
+}
+
+// ---- multi-device batch (SURVEY 8b `n_devices`, 8e) --------------------------------------------
+// Row i of the caller's table goes to context i mod n_ctx (interleaved: per-point cost correlates with s and theta,
+// so contiguous blocks of a sorted table would load one GPU with all the expensive points).  One host thread per
+// context gathers its shard, runs the ordinary single-device call and scatters its rows back into the caller's
+// [n][8] table; there is no exchange between devices while they compute, and a point's result does not depend on
+// which device evaluated it, so the table is bit-identical for every n_ctx.  Contexts that sit on the SAME device
+// (a 1-GPU box rehearsing the path) run one after the other: two persistent grids on one device time-slice badly.
+static std::mutex g_device_mu[64];
+
+extern "C" int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx, int kind, size_t n,
+                                            const double *s, const double *theta, const double *const *params,
+                                            uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work)
+{
+    if (!ctxs || n_ctx < 1 || n_ctx > 64 || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
+    for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return RIMPHONY_EINVAL;
+    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;
-    if (!s || !theta) return RIMPHONY_EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    if (!s || !theta || !out) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];
-    const size_t need_in = n * (size_t) (2 + np);
-    if (c->in_cap < need_in) {
-        if (c->d_in) (void) hipFree(c->d_in);
-        c->d_in = nullptr; c->in_cap = 0;
-        if (hipMalloc(&c->d_in, need_in * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
-        c->in_cap = need_in;
+    for (int k = 0; k < np; k++) if (!params[k]) return RIMPHONY_EINVAL;
+    if (n_ctx == 1) return rimphony_batch_compute_ex(ctxs[0], kind, n, s, theta, params, coeff_mask, precision, out, status, work);
+
+    std::vector<int> rcs((size_t) n_ctx, RIMPHONY_OK);
+    std::vector<std::string> errs((size_t) n_ctx);
+    auto run = [&](int r) {
+        const size_t m = (n - (size_t) r + (size_t) n_ctx - 1) / (size_t) n_ctx;      // rows r, r + n_ctx, ...
+        if (m == 0) return;
+        try {
+            std::vector<double> in((size_t) (2 + np) * m), o(m * 8);
+            std::vector<int32_t> stt(status ? m * 8 : 0);
+            std::vector<uint64_t> wk(work ? m * 8 : 0);
+            const double *pp[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+            for (size_t j = 0; j < m; j++) {
+                const size_t i = (size_t) r + j * (size_t) n_ctx;
+                in[j] = s[i];
+                in[m + j] = theta[i];
+                for (int k = 0; k < np; k++) in[(size_t) (2 + k) * m + j] = params[k][i];
+            }
+            for (int k = 0; k < np; k++) pp[k] = in.data() + (size_t) (2 + k) * m;
+            int rc;
+            {
+                const int dev = ctxs[r]->device;
+                std::lock_guard<std::mutex> same_device(g_device_mu[dev & 63]);
+                rc = rimphony_batch_compute_ex(ctxs[r], kind, m, in.data(), in.data() + m, pp, coeff_mask, precision,
+                                               o.data(), status ? stt.data() : nullptr, work ? wk.data() : nullptr);
+            }
+            if (rc) { rcs[(size_t) r] = rc; errs[(size_t) r] = rimphony_last_error(); return; }
+            for (size_t j = 0; j < m; j++) {
+                const size_t i = (size_t) r + j * (size_t) n_ctx;
+                memcpy(out + i * 8, o.data() + j * 8, 8 * sizeof(double));
+                if (status) memcpy(status + i * 8, stt.data() + j * 8, 8 * sizeof(int32_t));
+                if (work) memcpy(work + i * 8, wk.data() + j * 8, 8 * sizeof(uint64_t));
+            }
+        } catch (const std::bad_alloc &) {
+            rcs[(size_t) r] = RIMPHONY_ENOMEM;
+        }
+    };
+    std::vector<std::thread> threads;
+    try {
+        for (int r = 1; r < n_ctx; r++) threads.emplace_back(run, r);
+    } catch (...) {
+        for (auto &t : threads) t.join();
+        return RIMPHONY_ENOMEM;
     }
-    if (c->out_cap < n) {
-        if (c->d_out) (void) hipFree(c->d_out);
-        if (c->d_status) (void) hipFree(c->d_status);
-        c->d_out = nullptr; c->d_status = nullptr; c->out_cap = 0;
-        if (hipMalloc(&c->d_out, n * 8 * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
-        if (hipMalloc(&c->d_status, n * 8 * sizeof(int32_t)) != hipSuccess) return RIMPHONY_ENOMEM;
-        c->out_cap = n;
-    }
-    HIP_TRY(hipMemcpy(c->d_in, s, n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_in + n, theta, n * sizeof(double), hipMemcpyHostToDevice));
-    const double *dp[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
-    for (int k = 0; k < np; k++) {
-        if (!params[k]) return RIMPHONY_EINVAL;
-        HIP_TRY(hipMemcpy(c->d_in + (size_t) (2 + k) * n, params[k], n * sizeof(double), hipMemcpyHostToDevice));
-        dp[k] = c->d_in + (size_t) (2 + k) * n;
-    }
-    int rc = rimphony_batch_compute_device(c, kind, n, c->d_in, c->d_in + n, dp, coeff_mask, c->d_out, c->d_status, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, c->d_out, n * 8 * sizeof(double), hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, c->d_status, n * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    run(0);
+    for (auto &t : threads) t.join();
+    for (int r = 0; r < n_ctx; r++)
+        if (rcs[(size_t) r]) {
+            if (!errs[(size_t) r].empty()) rim_set_last_error("rimphony_batch_compute_multi", errs[(size_t) r].c_str());
+            return rcs[(size_t) r];
+        }
     return RIMPHONY_OK;
+}
+
+// Where did the coefficients of a table end?  hist[slot][b] = number of rows whose status word of that slot has bit b
+// set (b = 0..6: the RIMPHONY_ST_* bits), hist[slot][7] = rows with status 0.
+__global__ void status_hist_kernel(const int32_t *status, size_t n, unsigned long long *hist)
+{
+    __shared__ unsigned h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < n * 8; idx += (size_t) gridDim.x * blockDim.x) {
+        const int slot = (int) (idx & 7);
+        const int v = status[idx];
+        if (v == 0) atomicAdd(&h[slot * 8 + 7], 1u);
+        for (int b = 0; b < 7; b++) if (v & (1 << b)) atomicAdd(&h[slot * 8 + b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long) h[threadIdx.x]);
+}
+
+extern "C" int rimphony_status_histogram_device(rimphony_ctx *c, size_t n, const int32_t *d_status, uint64_t hist[64], void *stream)
+{
+    if (!c || !hist) return RIMPHONY_EINVAL;
+    for (int k = 0; k < 64; k++) hist[k] = 0;
+    if (n == 0) return RIMPHONY_OK;
+    if (!d_status) return RIMPHONY_EINVAL;
+    std::lock_guard<std::mutex> lock(*c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t) stream;
+    // the histogram words live behind the counter words of the queue allocation? no: they are read back here, so a
+    // private scratch allocation keeps this call independent of a batch in flight
+    unsigned long long *d_hist = nullptr;
+    if (hipMalloc(&d_hist, 64 * sizeof(unsigned long long)) != hipSuccess) return RIMPHONY_ENOMEM;
+    int rc = RIMPHONY_OK;
+    if (hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned long long), st) != hipSuccess) rc = RIMPHONY_EHIP;
+    if (!rc) {
+        const size_t total = n * 8;
+        const unsigned blocks = (unsigned) ((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(status_hist_kernel, dim3(blocks), dim3(256), 0, st, d_status, n, d_hist);
+        if (hipGetLastError() != hipSuccess) rc = RIMPHONY_EHIP;
+    }
+    if (!rc && hipMemcpyAsync(hist, d_hist, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) rc = RIMPHONY_EHIP;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = RIMPHONY_EHIP;
+    (void) hipFree(d_hist);
+    if (rc == RIMPHONY_EHIP) rim_set_last_error("rimphony_status_histogram_device", "HIP call failed");
+    return rc;
 }
 
 extern "C" int rimphony_highfreq_batch_device(rimphony_ctx *c, int kind, size_t n, const double *d_s, const double *d_theta,
@@ -1394,40 +1676,14 @@ extern "C" int rimphony_bessel_batch_device(rimphony_ctx *c, size_t count, const
     return RIMPHONY_OK;
 }
 
-// ---- the reference's scalar FFI seam (leung-bessel/src/lib.rs:36-42) -----------------------
-// `extern { fn pkgw_bessel_j(n: c_double, x: c_double) -> c_double; fn pkgw_bessel_dj(..) }`: the same
-// two C symbols, so the reference's leung-bessel crate can link this library instead of bessel.c.
-// Each call is one single-element kernel launch on the current device (tens of microseconds):
-// correct drop-in, not a fast path -- use rimphony_bessel_batch_device for arrays.  Errors (no GPU,
-// HIP failure) follow the seam's convention: NaN.
-static int scalar_bessel(double n, double x, double *j, double *dj)
-{
-    static std::mutex mu;
-    static double *d_buf = nullptr;      // {n, x, j, dj}
-    std::lock_guard<std::mutex> lock(mu);
-    if (!d_buf && hipMalloc(&d_buf, 4 * sizeof(double)) != hipSuccess) { d_buf = nullptr; return RIMPHONY_EHIP; }
-    const double in[2] = { n, x };
-    if (hipMemcpy(d_buf, in, sizeof in, hipMemcpyHostToDevice) != hipSuccess) return RIMPHONY_EHIP;
-    hipLaunchKernelGGL(bessel_kernel, dim3(1), dim3(256), 0, (hipStream_t) 0, (size_t) 1, d_buf, d_buf + 1, d_buf + 2, d_buf + 3);
-    if (hipGetLastError() != hipSuccess) return RIMPHONY_EHIP;
-    double out[2];
-    if (hipMemcpy(out, d_buf + 2, sizeof out, hipMemcpyDeviceToHost) != hipSuccess) return RIMPHONY_EHIP;
-    *j = out[0];
-    *dj = out[1];
-    return RIMPHONY_OK;
-}
-
-extern "C" double pkgw_bessel_j(double n, double x)
-{
-    double j, dj;
-    return scalar_bessel(n, x, &j, &dj) == RIMPHONY_OK ? j : RIM_NAN;
-}
-
-extern "C" double pkgw_bessel_dj(double n, double x)
-{
-    double j, dj;
-    return scalar_bessel(n, x, &j, &dj) == RIMPHONY_OK ? dj : RIM_NAN;
-}
+// ---- the reference's scalar FFI seam (leung-bessel/src/lib.rs:36-42, 56-75) -------------------
+// `extern { fn pkgw_bessel_j(n: c_double, x: c_double) -> c_double; fn pkgw_bessel_dj(..) }`: the same two C symbols,
+// so the reference's leung-bessel crate can link this library instead of bessel.c.  They are the HOST build of the
+// very functions the kernels inline (dev_bessel.h is __host__ __device__): no HIP call, no GPU needed, reentrant,
+// a few hundred nanoseconds per call like the C code they replace, and -- the rounding contract of detmath.h --
+// the same bits as rimphony_bessel_batch_device returns for the same arguments.  Errors are NaN, as in bessel.c.
+extern "C" double pkgw_bessel_j(double n, double x) { return rim::bessel_j(n, x); }
+extern "C" double pkgw_bessel_dj(double n, double x) { return rim::bessel_dj(n, x); }
 
 static int fill_point_args(int kind, const double *params, int coeff, int stokes, int negative_lobe,
                            double s, double theta, PointArgs &pa)

@@ -39,11 +39,14 @@
 #else
 #define RIM_DYN_LDS 0
 #endif
+// A failed HIP call: remember what failed where rimphony_last_error() can find it (thread-local; a library does
+// not print) and return RIMPHONY_EHIP.
+void rim_set_last_error(const char *what, const char *detail);
 #define HIP_TRY(expr)                                                            \
     do {                                                                         \
         hipError_t e_ = (expr);                                                  \
         if (e_ != hipSuccess) {                                                  \
-            fprintf(stderr, "rimphony_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            rim_set_last_error(#expr, hipGetErrorString(e_));                    \
             return RIMPHONY_EHIP;                                                \
         }                                                                        \
     } while (0)

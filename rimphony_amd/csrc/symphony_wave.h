@@ -267,6 +267,7 @@ __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistPara
                                               double &val0, int &st0, double &val1, int &st1)
 {
     const int lane = g.lane;
+    RIM_HIT(21);
     RIM_PROF_T(t_setup);
     // ---- setup: every lane computes the data of its half's request, lanes 0 and 32 file them in LDS ----
     const bool second = g.half != 0 && have1;

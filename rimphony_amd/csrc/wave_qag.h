@@ -312,6 +312,7 @@ __device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane
     wv_sync();   // make lane 0's store writes visible to the whole wave
     int imax = 0;
     if (q.size > 2) {
+        RIM_HIT(2);
         // wave-wide argmax over (error, stamp)
         double be = -1.0;
         int bs = -1, bi = 0;
@@ -333,6 +334,7 @@ __device__ __forceinline__ void qag_pick(QagState &q, const IStore &st, int lane
         if (__builtin_popcountll(holders) == 1) {
             bi = wv_readlane(bi, __builtin_ffsll((long long) holders) - 1);
         } else {
+            RIM_HIT(3);
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
                 const double oe = wv_shfl_xor(be, m);
@@ -580,6 +582,7 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
                 hb_store(park->hb + 4, (unsigned long long) q.iteration);
             }
         }
+        RIM_HIT(0); if (phase == 0) RIM_HIT(1);
         RIM_PROF_T(t_int);
         const double fv = f(x, active, second != flip);
         RIM_PROF_ADD(1, t_int);
@@ -609,6 +612,7 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
         if (!finished) continue;
 
         for (;;) {                   // integral `cur` is complete
+            RIM_HIT(22);
             if (lane == 0) park->ctr.inner_qags += 1;
             if (cur == 0) { r0 = uni(q.result); qs0 = uni(q.status); } else { r1 = uni(q.result); qs1 = uni(q.status); }
             if (abserr_out) abserr_out[cur] = q.abserr;

@@ -72,3 +72,26 @@ def make_batch(config, n, start=0):
         k = _lin(uniform01(seed, idx, 4), 0.0, 3.0)
         params = [kappa, width, k, 1e10 * ones]
     return kind, mask, s, theta, params
+
+
+def compare_tables(got, ref, mask=0xFF):
+    """Relative-error distribution of one [n][8] table against another over the slots selected in `mask`:
+    median / p99 / max of |got - ref| / |ref| where both are finite, the fraction of coefficients within 1e-6, and
+    how many coefficients are NaN on exactly one side (the NaN pattern is part of the result: a NaN is the
+    reference's way of reporting a failed quadrature, symphony.rs:115-117, 380)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    slots = [k for k in range(8) if mask & (1 << k)]
+    g, r = got[:, slots], ref[:, slots]
+    both = np.isfinite(g) & np.isfinite(r)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.abs(g - r) / np.abs(r)
+    rel = np.where(r == g, 0.0, rel)[both]
+    res = {"rows": int(got.shape[0]), "coefficients": int(g.size), "both_finite": int(both.sum()),
+           "nan_only_here": int((~np.isfinite(g) & np.isfinite(r)).sum()),
+           "nan_only_there": int((np.isfinite(g) & ~np.isfinite(r)).sum()),
+           "nan_both": int((~np.isfinite(g) & ~np.isfinite(r)).sum())}
+    if rel.size:
+        res.update({"median": float(np.median(rel)), "p99": float(np.quantile(rel, 0.99)), "max": float(rel.max()),
+                    "within_1e-6": float((rel <= 1e-6).mean()), "bit_identical": float((rel == 0).mean())})
+    return res

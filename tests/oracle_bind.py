@@ -17,7 +17,8 @@ class Dist(ctypes.Structure):
 class Counters(ctypes.Structure):
     _fields_ = [(n, c_uint64) for n in (
         "integrand_evals", "gk_evals", "inner_qag_calls", "outer_gk_evals", "outer_qag_calls", "deriv_calls",
-        "max_inner_size", "max_outer_size", "bessel_calls", "norm_evals")]
+        "max_inner_size", "max_outer_size", "bessel_calls", "norm_evals",
+        "hey_nr_samples", "hey_qr_i_samples", "hey_qr_jy_samples", "hey_series_terms", "hey_series_calls")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -193,3 +193,87 @@ dist.destroy_process_group()
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "OK" in r.stdout
+
+
+def test_scalar_bessel_seam_is_host_code_and_matches_oracle(oracle):
+    """pkgw_bessel_j / pkgw_bessel_dj (leung-bessel/src/lib.rs:36-42): exported by the product library as HOST code --
+    they work here, without a GPU -- and return the oracle's bits, including the x > n side, the integer orders
+    below 30 and the error conventions of bessel.c (NaN for non-integer n < 30 and for n >= 1e15 in dj)."""
+    from rimphony_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(11)
+    n = np.concatenate([np.exp(rng.uniform(math.log(30), math.log(1e12), 6000)), rng.integers(0, 30, 1000).astype(float)])
+    x = n * rng.uniform(0.2, 1.3, n.size)
+    for a, b in zip(n, x):
+        assert _same(lib.pkgw_bessel_j(a, b), oracle.rimo_bessel_j(a, b)), (a, b)
+        assert _same(lib.pkgw_bessel_dj(a, b), oracle.rimo_bessel_dj(a, b)), (a, b)
+    # leung-bessel/src/lib.rs:83-85 smoke values (n < 30 -> integer-order J_n)
+    assert abs(lib.pkgw_bessel_j(1., 1.) - 0.44005058574493355) < 1e-15
+    assert math.isnan(lib.pkgw_bessel_j(12.5, 3.))           # bessel.c:327-331
+    assert math.isnan(lib.pkgw_bessel_dj(1e15, 5e14))        # bessel.c:382-388
+    assert math.isnan(lib.pkgw_bessel_j(-1., 3.))
+
+
+def test_scalar_bessel_seam_call_rate():
+    """The seam replaces a ~100-200 ns C call: it must stay a plain host function."""
+    import time
+    from rimphony_amd import capi
+    lib = capi.load()
+    f = lib.pkgw_bessel_j
+    t0 = time.perf_counter()
+    for i in range(100000):
+        f(1000. + i, 900. + i)
+    rate = 100000 / (time.perf_counter() - t0)
+    assert rate > 2e5, rate          # through ctypes; ~7e6/s from C (tools/ not needed: see DESIGN.md)
+
+
+def test_spawn_ranks_runs_a_gloo_world_without_torchrun(tmp_path):
+    """rimphony_amd.launch.spawn_ranks -- what `python bench.py --gpus N` uses when no launcher set WORLD_SIZE:
+    N child processes with the rendezvous variables, rank 0's stdout is the parent's, worst exit code returned."""
+    script = tmp_path / "w.py"
+    script.write_text(r'''
+import os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+if rank == 0:
+    print("SUM", t.item(), os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"])
+dist.destroy_process_group()
+sys.exit(int(sys.argv[1]) if rank == 1 else 0)
+''')
+    code = ("import sys; sys.path.insert(0, %r); from rimphony_amd import launch; "
+            "sys.exit(launch.spawn_ranks(2, [%r, sys.argv[1]], timeout=300))" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SUM 3.0 2 127.0.0.1" in r.stdout
+    r = subprocess.run([sys.executable, "-c", code, "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 3
+
+
+def test_bench_parent_never_touches_the_gpu():
+    """bench.py --gpus N>1 without a launcher must spawn its ranks before anything initialises the GPU: the parent
+    path may not import torch (static check of the code in front of the spawn)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("launch.spawn_ranks(")]
+    assert "import torch" not in head.split("def main")[1]
+
+
+def test_api_refuses_bad_device_inputs():
+    """compute_batch_device takes raw pointers: strided views, wrong dtype, wrong length and host tensors are
+    refused before any pointer reaches the C ABI (no GPU needed for these checks)."""
+    import torch
+    from rimphony_amd import api
+    ctx = object.__new__(api.Context)      # no device: only the argument checks run
+    ctx.device = 0
+    good = torch.zeros(4, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        ctx.compute_batch_device(0, good, good, [good] * 3)              # wrong number of parameter arrays
+    with pytest.raises(ValueError):
+        ctx.compute_batch_device(9, good, good, [good] * 4)              # unknown kind
+    with pytest.raises(ValueError):
+        ctx.compute_batch_device(0, good, good, [good] * 4)              # host tensors
+    with pytest.raises(TypeError):
+        ctx.compute_batch_device(0, np.zeros(4), good, [good] * 4)       # not a tensor

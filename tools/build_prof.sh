@@ -5,3 +5,6 @@ cd "$(dirname "$0")/.." && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -sha
 # the same with only the cooperative-tail counters (tools/ab_assist.py):
 cd "$(dirname "$0")/.." && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -disable-machine-licm \
   -DRIM_COOP_DIAG -Iinclude -Irimphony_amd/csrc rimphony_amd/csrc/rimphony_hip.hip rimphony_amd/csrc/rimphony_diag.hip -o rimphony_amd/librimphony_diag.so
+# execution counters instead of timers (tools/hit_profile.py):
+cd "$(dirname "$0")/.." && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -disable-machine-licm \
+  -DRIM_PROF -DRIM_PROF_COUNTS -Iinclude -Irimphony_amd/csrc rimphony_amd/csrc/rimphony_hip.hip rimphony_amd/csrc/rimphony_diag.hip -o rimphony_amd/librimphony_hits.so
