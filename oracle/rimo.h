@@ -155,6 +155,22 @@ int rimo_qag_selftest(int family, double p0, double p1, double a, double b, doub
 
 const char *rimo_build_flavour(void);
 
+/* Investigation knobs (tools/ only; every test and the bench run with the defaults = the reference's values):
+ * tolerances and truncation parameters of symphony.rs / heyvaerts.rs that the reference hard-codes, and this
+ * restatement's own caps on the marching loops.  NULL restores the defaults.  Process-global, not thread-safe to
+ * change while a batch runs.  exact_bessel != 0 replaces the Leung approximations by glibc's jn() for integer orders
+ * (only meaningful for the discrete harmonics: what an exact J_n would change). */
+typedef struct {
+    double epsrel_gamma;    /* 1e-3   symphony.rs:375-380                    */
+    double epsrel_n;        /* 1e-3   symphony.rs:264-269                    */
+    double tail_tolerance;  /* 1e5    symphony.rs:202, 225                   */
+    int n_discrete;         /* 30     symphony.rs:96 (N_MAX)                 */
+    int max_chunks;         /* 4096   this restatement's cap   */
+    int hey_max_steps;      /* 4096   the same for heyvaerts.rs:102,134,161  */
+} rimo_tuning;
+void rimo_set_tuning(const rimo_tuning *t);
+void rimo_get_tuning(rimo_tuning *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -313,6 +313,9 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
 
     (void) coeff;
     if (stokes != RIMO_STOKES_Q && stokes != RIMO_STOKES_V) return RIM_NAN;
+    rimo_tuning tuning;
+    rimo_get_tuning(&tuning);
+    const int hey_max_steps = tuning.hey_max_steps;
 
     st.d = d;
     st.stokes = stokes;
@@ -338,7 +341,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
 
     steps = 0;
     while (keep_going) {
-        if (++steps > HEY_MAX_STEPS) goto done;
+        if (++steps > hey_max_steps) goto done;
         if (nr_val != 0.) {
             const double rel_deriv = deriv_of(&st, nr_outer_integrand, pomega_right);
             if (rel_deriv == 0. || m_fabs(1. / (rel_deriv * delta_right)) > DELTA_SCALE_FACTOR)
@@ -355,7 +358,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
     keep_going = 1;
     steps = 0;
     while (keep_going) {
-        if (++steps > HEY_MAX_STEPS) goto done;
+        if (++steps > hey_max_steps) goto done;
         const double rel_deriv = deriv_of(&st, nr_outer_integrand, pomega_left);
         if (rel_deriv == 0. || m_fabs(1. / (rel_deriv * delta_left)) > DELTA_SCALE_FACTOR)
             delta_left *= DELTA_SCALE_FACTOR;
@@ -373,7 +376,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
         keep_going = 1;
         steps = 0;
         while (keep_going) {
-            if (++steps > HEY_MAX_STEPS) goto done;
+            if (++steps > hey_max_steps) goto done;
             if (qr_val != 0.) {
                 const double rel_deriv = deriv_of(&st, qr_outer_integrand, sigma_low);
                 if (rel_deriv == 0. || m_fabs(1. / (rel_deriv * delta_sigma)) > DELTA_SCALE_FACTOR) {

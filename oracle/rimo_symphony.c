@@ -22,6 +22,11 @@
  * relies on pkgw_bessel_dj going NaN at n >= 1e15; the kernels share this cap */
 #define RIMO_MAX_CHUNKS 4096
 
+static const rimo_tuning TUNING_DEFAULT = { 1e-3, 1e-3, 1e5, 30, RIMO_MAX_CHUNKS, 4096 };
+static rimo_tuning g_tuning = { 1e-3, 1e-3, 1e5, 30, RIMO_MAX_CHUNKS, 4096 };
+void rimo_set_tuning(const rimo_tuning *t) { g_tuning = t ? *t : TUNING_DEFAULT; }
+void rimo_get_tuning(rimo_tuning *t) { *t = g_tuning; }
+
 typedef struct {
     const rimo_dist *d;
     int coeff, stokes;
@@ -115,7 +120,7 @@ static double gamma_integral(sym_state *st, double n)
     double result, abserr;
     uint64_t nev = 0;
     st->cur_n = n;
-    int status = rimo_qag(gamma_integrand_cb, st, gamma0, gamma1, 0., 1e-3, 5000, st->gamma_ws,
+    int status = rimo_qag(gamma_integrand_cb, st, gamma0, gamma1, 0., g_tuning.epsrel_gamma, 5000, st->gamma_ws,
                           &result, &abserr, &nev);
     if (st->c) {
         st->c->gk_evals += nev;
@@ -134,7 +139,7 @@ static double gamma_integral_cb(double n, void *ctx)
 static double n_integration(sym_state *st, double n_start, int *failed)
 {
     double ans = 0., contrib = 0., delta_n = 1e5, incr_step_factor = 10.;
-    const double DERIV_TOL = 1e-5, TOLERANCE = 1e5;
+    const double DERIV_TOL = 1e-5, TOLERANCE = g_tuning.tail_tolerance;
     rimo_workspace *n_ws = rimo_workspace_alloc(1000);
     int chunks = 0;
 
@@ -148,7 +153,7 @@ static double n_integration(sym_state *st, double n_start, int *failed)
     while (m_fabs(contrib) >= m_fabs(ans / TOLERANCE)) {
         double deriv, derr;
 
-        if (++chunks > RIMO_MAX_CHUNKS) { *failed = 1; break; }
+        if (++chunks > g_tuning.max_chunks) { *failed = 1; break; }
 
         rimo_deriv_central(gamma_integral_cb, st, n_start, 1e-10 * n_start, &deriv, &derr);
         if (st->c) st->c->deriv_calls++;
@@ -162,7 +167,7 @@ static double n_integration(sym_state *st, double n_start, int *failed)
         {
             double abserr;
             uint64_t nev = 0;
-            int status = rimo_qag(gamma_integral_cb, st, n_start, n_start + delta_n, 0., 1e-3, 1000, n_ws,
+            int status = rimo_qag(gamma_integral_cb, st, n_start, n_start + delta_n, 0., g_tuning.epsrel_n, 1000, n_ws,
                                   &contrib, &abserr, &nev);
             if (st->c) {
                 st->c->outer_gk_evals += nev;
@@ -207,7 +212,7 @@ static void sym_init(sym_state *st, const rimo_dist *d, int coeff, int stokes, d
 
 double rimo_symphony(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c)
 {
-    const double N_MAX = 30.;
+    const double N_MAX = (double) g_tuning.n_discrete;
     sym_state st;
     double ans = 0.;
     int failed;

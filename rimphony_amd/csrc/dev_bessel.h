@@ -61,9 +61,15 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
     if (f_exp < -760. && rim_fabs(f_factor) < 1e6) { RIM_HIT(11); return f_factor * 0.; }
     if (a > 690.) {
         RIM_HIT(12);
-        const double sign_f = (f_factor < 0) ? -1. : 1.;
-        const double log_f = rim_log(rim_fabs(f_factor));
-        if (log_f * f_exp < 0.) return sign_f * rim_exp(log_f + f_exp);
+        // bessel.c:44-48 takes sign(f) exp(log|f| + e) when log|f| e < 0, else f exp(e).  The product is negative
+        // exactly when |f| < 1 and e > 0, or |f| > 1 and e < 0 (log|f| has the sign of |f| - 1, |e| > 690 here, NaN
+        // compares false both ways): the logarithm is only taken where its value is used.  For the Meissel prefactor,
+        // |f| < 1 and e < 0 -- the second arm -- is the common case.
+        const double af = rim_fabs(f_factor);
+        if ((af < 1. && f_exp > 0.) || (af > 1. && f_exp < 0.)) {
+            const double sign_f = (f_factor < 0) ? -1. : 1.;
+            return sign_f * rim_exp(rim_log(af) + f_exp);
+        }
         return f_factor * rim_exp(f_exp);
     }
     RIM_HIT(13);
@@ -386,8 +392,12 @@ RIM_DEV void debye_eps_pair(double n0, double n1, double x, double *r0, double *
     p1 = rim_fma(p1, ez1, c);
 
     const double den = RIM_PI * t146 * 0.58354968672000000e17;
-    *r0 = p0 / den;
-    *r1 = p1 / den;
+    // Both quotients have the same divisor.  30 <= x < 1e15 in the integrator (the only caller), so den = 1.8e17 x^(16/3)
+    // is a normal number below 1e98, and the quotients are Bessel values of the transition region (~ n^(-1/3)) or
+    // exactly 0: moderate operands, for which the bare division sequence returns the bits of `/` (detmath.h).  Its
+    // first five instructions -- the refined reciprocal -- depend on den only and are shared by the compiler.
+    *r0 = rim_div_moderate(p0, den);
+    *r1 = rim_div_moderate(p1, den);
 }
 
 // pkgw_bessel_j for n >= 30 given the hoisted order data, in three steps:
@@ -436,6 +446,44 @@ RIM_DEV LeungSel leung_select(const LeungOrder &o, double x)
         }
     }
     return s;
+}
+
+// The same decision as a small integer, for the integrand (no struct of flags to keep per order):
+//   bit 0 Debye expansion needed, bit 1 Meissel "first" needed, bit 2 linear blend of the two (pos = weight of
+//   Meissel), bit 3 no value (NaN argument, or the Meissel "second" region, which the integrator cannot reach).
+enum { LSEL_DEBYE = 1, LSEL_MEISSEL = 2, LSEL_BLEND = 4, LSEL_NONE = 8 };
+
+RIM_DEV int leung_select_code(const LeungOrder &o, double x, double &pos)
+{
+    const double n = o.n;
+    pos = 0.;
+    if (!(x >= 0)) return LSEL_NONE;
+    if (x < n) {
+        const double r = rim_div_by(n - x, n, o.ninv);
+        if (r < o.r_lo_dn) return LSEL_DEBYE;
+        if (r > o.r_hi_up) return LSEL_MEISSEL;
+        RIM_HIT(4);
+        const double eta = rim_log10_region(r);
+        if (eta < o.thr_lo) return LSEL_DEBYE;
+        if (eta > o.thr_hi) return LSEL_MEISSEL;
+        RIM_HIT(18);
+        // (eta - thr_lo) / (0.295966 - 0.174857): a literal divisor, the exact 3-operation division
+        pos = rim_div_by(eta - o.thr_lo, 0.295966 - 0.174857, 1. / (0.295966 - 0.174857));
+        return LSEL_DEBYE | LSEL_MEISSEL | LSEL_BLEND;
+    }
+    if (x == n) return LSEL_DEBYE;
+    RIM_HIT(17);
+    const double r = (x - n) / x;
+    if (r < o.rp_dn) return LSEL_DEBYE;
+    if (r > o.rp_up) return LSEL_NONE;
+    return rim_log10_region(r) < o.thr_plus_lo ? LSEL_DEBYE : LSEL_NONE;
+}
+
+RIM_DEV double leung_combine_code(int code, double pos, double debye, double meissel1)
+{
+    if (code & LSEL_NONE) return RIM_NAN;
+    if (code & LSEL_BLEND) return debye * (1 - pos) + meissel1 * pos;
+    return (code & LSEL_DEBYE) ? debye : meissel1;
 }
 
 RIM_DEV double leung_combine(const LeungSel &s, double debye, double meissel1)

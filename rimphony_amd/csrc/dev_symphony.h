@@ -165,40 +165,25 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
     const double n = so.n;
     double jv0 = 0., jv1 = 0.;
     if (!so.np1_small) {
-        // which expansions do the two orders need at this z?
+        // which expansions do the two orders need at this z?  (order n only if it is >= 30)
         RIM_PROF_T(t_sel);
-        LeungSel s0, s1;
-        s0.need_debye = s0.need_meissel = s0.blend = s0.unsupported = s0.nan = false; s0.pos = 0.;
-        s1 = s0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-        for (int w = 0; w < 2; w++) {
-            if (w == 0 && so.small) continue;
-            const LeungSel s = leung_select(so.o[w], z);
-            if (w) s1 = s; else s0 = s;
-        }
+        double pos0 = 0., pos1 = 0.;
+        int c0 = 0;
+        if (!so.small) c0 = leung_select_code(so.o[0], z, pos0);
+        const int c1 = leung_select_code(so.o[1], z, pos1);
         RIM_PROF_ADD(3, t_sel);
         // Debye for both orders in one go (they share everything but x - n), Meissel order by order
         RIM_PROF_T(t_deb);
         double deb0 = 0., deb1 = 0.;
-        if (s0.need_debye || s1.need_debye) debye_eps_pair(so.o[0].n, so.o[1].n, z, &deb0, &deb1);
+        if ((c0 | c1) & LSEL_DEBYE) debye_eps_pair(so.o[0].n, so.o[1].n, z, &deb0, &deb1);
         RIM_PROF_ADD(4, t_deb);
         RIM_PROF_T(t_mei);
         double mei0 = 0., mei1 = 0.;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
-        for (int w = 0; w < 2; w++) {
-            const bool need = w ? s1.need_meissel : s0.need_meissel;
-            if (need) {
-                const double v = meissel_first(so.o[w], z);
-                if (w) mei1 = v; else mei0 = v;
-            }
-        }
+        if (c0 & LSEL_MEISSEL) mei0 = meissel_first(so.o[0], z);
+        if (c1 & LSEL_MEISSEL) mei1 = meissel_first(so.o[1], z);
         RIM_PROF_ADD(5, t_mei);
-        if (!so.small) jv0 = leung_combine(s0, deb0, mei0);
-        jv1 = leung_combine(s1, deb1, mei1);
+        if (!so.small) jv0 = leung_combine_code(c0, pos0, deb0, mei0);
+        jv1 = leung_combine_code(c1, pos1, deb1, mei1);
     }
     if (so.small) {
         // the reference returns NaN for non-integer n < 30 (bessel.c:327-331)

@@ -65,6 +65,26 @@ __device__ __forceinline__ unsigned long long wv_ballot(bool p) { return __ballo
 template <int M> inline double wv_swz_xor(double v) { return wv_shfl_xor(v, M); }     // emulator: same exchange
 #endif
 
+// A wave-uniform decision taken from lane 0's operands (the bookkeeping of the lean QAG below computes in "lane 0's
+// view": every lane executes the arithmetic, lane 0 holds the operands that matter).  One v_cmp into an SGPR pair and
+// scalar bit tests; the result is provably uniform, so the branch on it is a scalar branch.
+__device__ __forceinline__ bool lane0(bool c) { return (wv_ballot(c) & 1ull) != 0; }
+// lane 0's (a && b): two compares into scalar masks and scalar logic (a fused condition would be materialised as a
+// 0/1 vector register and compared again)
+__device__ __forceinline__ bool lane0_and(bool a, bool b) { return (wv_ballot(a) & wv_ballot(b) & 1ull) != 0; }
+
+// max(a, b) of two non-NaN doubles in one instruction (__builtin_fmax adds a canonicalising v_max per operand)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIM_WAVE_EMU)
+__device__ __forceinline__ double rim_vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+__device__ __forceinline__ double rim_vmax(double a, double b) { return __builtin_fmax(a, b); }
+#endif
+
 enum {
     QAG_SUCCESS = 0, QAG_EFAILED = 5, QAG_EMAXITER = 11, QAG_EBADTOL = 13, QAG_EROUND = 18, QAG_ESING = 21,
     QAG_ESTORE = 1001   // LDS subinterval store exhausted (not a GSL code)
@@ -436,7 +456,15 @@ struct WaveCounters {
 
 // LDS scratch of one wave's QAG: the bookkeeping state is parked here while the
 // integrand runs, so that the integrand has the vector register file to itself.
+// State of the lean (LDS-resident list) QAG that does not fit uniform integer registers: the running sums, and the
+// first-rule result of integral 1 while integral 0 runs.
+struct LeanPark {
+    double area, errsum;
+    double fb[4];             // result, abserr, resabs, resasc of integral 1's first rule application
+};
+
 struct QagPark {
+    LeanPark lean;
     QagState q;
     LeungOrder ord[4];        // order records (n, n + 1) of the one or two gamma-integrals in flight (SymOrder)
     WaveCounters ctr;
@@ -525,6 +553,93 @@ __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st
     }
 }
 
+// ---- lean QAG: the subinterval list in LDS, the bookkeeping in vector registers ----------------------------
+//
+// The general functions above keep the QAG state wave-uniform in scalar registers.  gfx950 has no scalar fp64 ALU, so
+// every uniform fp64 operation is a full vector instruction anyway, and feeding it from scalar registers costs extra
+// moves (a VALU instruction takes one scalar operand), readlanes to make the rule sums uniform, moves again to store
+// them, and the whole state is copied to LDS and back around every integrand call: ~380 of the ~1600 vector
+// instructions of a pass of the Symphony kernel (profiles/r1_final_pmc_symphony_65536pts.json), which is issue-bound.
+// The lean form below does the same arithmetic in the same order (every value is the one the functions above
+// compute; tests/test_gpu_parity.py::test_qag_selftest_bit_exact and the end-to-end parity tests hold it to that)
+// with the operands where they already are:
+//   * the rule sums of child 1 sit in the lanes of half-wave 0, those of child 2 in half-wave 1; the bookkeeping is
+//     computed "in lane 0's view": child 1's values are lane 0's own registers, child 2's arrive by six readlanes
+//     (scalar operands, one per instruction), every lane executes the same instructions and only lane 0's results are
+//     used: decisions through lane0() (one compare into a scalar mask), stores by lane 0;
+//   * lanes 0 and 32 each file their own child in the list -- one ds_write per field with two active lanes;
+//   * the list lives in LDS as one interval per lane (lane i reads entry i), so the interval of largest error is a
+//     5-step max butterfly per half-wave, a scalar comparison of the two half-wave maxima (bit patterns of non-negative
+//     doubles order like integers) and a ballot; ties -- which GSL resolves through its sorted list -- take the general
+//     (error, stamp) reduction, as do lists that outgrow the LDS part (st.cap entries): the lean loop hands such an
+//     integral to the general functions, which continue it in the spill store;
+//   * the running sums area / errsum are two doubles in LDS (written by lane 0 from the registers they were computed
+//     in), the counters are scalar integers that stay in scalar registers across the integrand.
+
+// Index of the interval with the largest error among entries 0..size-1 (2 < size <= min(64, st.cap): one entry per
+// lane, all in LDS).
+__device__ __forceinline__ int lean_pick(const IStore &st, int size, int lane)
+{
+    const double e_l = lane < size ? st.e[lane] : -1.0;
+    double top = e_l;
+    top = rim_vmax(top, wv_swz_xor<1>(top));
+    top = rim_vmax(top, wv_swz_xor<2>(top));
+    top = rim_vmax(top, wv_swz_xor<4>(top));
+    top = rim_vmax(top, wv_swz_xor<8>(top));
+    top = rim_vmax(top, wv_swz_xor<16>(top));
+    // errors are >= +0 (or the -1 padding): their bit patterns order like signed integers
+    const long long t0 = (long long) rim_bits(readlane_d(top, 0));
+    const long long t1 = (long long) rim_bits(readlane_d(top, 32));
+    unsigned long long holders = wv_ballot(e_l == top);
+    holders &= (t1 > t0) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    if (t0 != t1 && __builtin_popcountll(holders) == 1) return __builtin_ffsll((long long) holders) - 1;
+    // tie (or a NaN error): largest error, latest insertion -- the order of GSL's sorted list
+    double be = e_l;
+    int bs = lane < size ? st.stamp[lane] : -1, bi = lane;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const double oe = wv_shfl_xor(be, m);
+        const int os = wv_shfl_xor(bs, m);
+        const int oi = wv_shfl_xor(bi, m);
+        if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+    }
+    return wv_readfirstlane(bi);
+}
+
+// The same for a list of any length (entries beyond st.cap live in the wave's global spill region): each lane scans
+// entries lane, lane + 64, ... and the wave reduces over (error, stamp).
+__device__ __forceinline__ int spill_pick(const IStore &st, int size, int lane)
+{
+    double be = -1.0;
+    int bs = -1, bi = 0;
+    for (int i = lane; i < size; i += 64) {
+        const double e = ist_e(st, i);
+        const int sp = ist_stamp(st, i);
+        if (e > be || (e == be && sp > bs)) { be = e; bs = sp; bi = i; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const double oe = wv_shfl_xor(be, m);
+        const int os = wv_shfl_xor(bs, m);
+        const int oi = wv_shfl_xor(bi, m);
+        if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+    }
+    return wv_readfirstlane(bi);
+}
+
+// One entry of the list at a wave-uniform index: LDS (typed accesses) or, behind a scalar branch, the spill region.
+struct IEntry { double a, b, r, e; };
+__device__ __forceinline__ IEntry ist_entry(const IStore &st, int i)
+{
+    IEntry en;
+    if (i < st.cap) { en.a = st.a[i]; en.b = st.b[i]; en.r = st.r[i]; en.e = st.e[i]; }
+    else {
+        const int j = i - st.cap;
+        en.a = st.g[j]; en.b = st.g[st.gcap + j]; en.r = st.g[2 * st.gcap + j]; en.e = st.g[3 * st.gcap + j];
+    }
+    return en;
+}
+
 // Two adaptive QAGs that share their first rule application.
 //
 // The first GK31 application of an integral uses 31 lanes, so two integrals are started together:
@@ -542,85 +657,186 @@ __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStor
                                               double *abserr_out = nullptr, int *size_out = nullptr)   // [2] each, optional
 {
     const int lane = g.lane;
-    QagState q;
-    qag_begin(q, epsabs, epsrel, limit);
-    int phase = 0;                   // 0: the joint first rule application, 1: bisections of integral `cur`
+    LeanPark *const lp = &park->lean;
+    enum { M_FIRST = 0, M_LEAN = 1 };
+    int mode = M_FIRST;              // M_FIRST: the joint first rule application; then bisections of integral `cur`
     int cur = 0;
-    double fb0 = 0., fb1 = 0., fb2 = 0., fb3 = 0.;
+    // the counters of the lean QAG: wave-uniform integers, in scalar registers across the integrand
+    int iteration = 0, size = 0, rt1 = 0, rt2 = 0, imax = 0;
+    unsigned n_pass = 0, n_samp = 0;
     r0 = 0.; r1 = 0.; qs0 = QAG_SUCCESS; qs1 = QAG_SUCCESS;
 
     for (;;) {
+        // ---------------- before the integrand: this pass's interval(s) ----------------
         double la, lb;
         bool active, second;
-        if (phase == 0) {
+        if (mode == M_FIRST) {
             second = g.half != 0 && have1;
             la = second ? a1 : a0;
             lb = second ? b1 : b0;
             active = g.node && (g.half == 0 || have1);
+            n_samp += have1 ? 62u : 31u;
         } else {
             RIM_PROF_T(t_pick);
-            qag_pick(q, st, lane);
+            wv_sync();               // the list entries written after the previous pass are visible to every lane
+            imax = 0;                // qpsrt: slot 0 while the list has <= 2 entries
+            if (size > 2) imax = (size <= 64 && size <= st.cap) ? lean_pick(st, size, lane) : spill_pick(st, size, lane);
             RIM_PROF_ADD(13, t_pick);
-            la = g.half ? q.a2 : q.a1;
-            lb = g.half ? q.b2 : q.b1;
+            double a_i, b_i;
+            if (imax < st.cap) { a_i = st.a[imax]; b_i = st.b[imax]; }
+            else { a_i = st.g[imax - st.cap]; b_i = st.g[st.gcap + (imax - st.cap)]; }
+            const double mid = 0.5 * (a_i + b_i);
+            la = g.half ? mid : a_i;
+            lb = g.half ? b_i : mid;
             second = cur != 0;
             active = g.node;
+            n_samp += 62u;
         }
+        n_pass += 1u;
         const double hl = 0.5 * (lb - la);
         const double x = 0.5 * (la + lb) + hl * gk_t(g);
-        if (lane == 0) {
-            // only what is live across the integrand (qag_uniformize_live reads exactly these back)
-            QagState &pq = park->q;
-            pq.area = q.area; pq.errsum = q.errsum;
-            pq.iteration = q.iteration; pq.rt1 = q.rt1; pq.rt2 = q.rt2;
-            pq.size = q.size; pq.imax = q.imax;
-            pq.a1 = q.a1; pq.b1 = q.b1; pq.b2 = q.b2; pq.r_i = q.r_i; pq.e_i = q.e_i;
-            park->ctr.samples += (phase == 0 && !have1) ? 31 : 62;
-            park->ctr.steps += 1;
-            if (park->hb) {
-                hb_store(park->hb + 3, park->ctr.steps);
-                hb_store(park->hb + 4, (unsigned long long) q.iteration);
-            }
-        }
-        RIM_HIT(0); if (phase == 0) RIM_HIT(1);
+        RIM_HIT(0); if (mode == M_FIRST) RIM_HIT(1);
         RIM_PROF_T(t_int);
         const double fv = f(x, active, second != flip);
         RIM_PROF_ADD(1, t_int);
-        RIM_PROF_T(t_unpark);
-        wv_sync();
-        q = park->q;
-        qag_uniformize_live(q, epsabs, epsrel, limit);
-        RIM_PROF_ADD(14, t_unpark);
 
+        // ---------------- after the integrand: apply the rule, book the result ----------------
         RIM_PROF_T(t_gk);
         const GKRes r = wave_gk31(fv, hl, g);
         RIM_PROF_ADD(11, t_gk);
         bool finished;
-        if (phase == 0) {
-            fb0 = readlane_d(r.result, 32); fb1 = readlane_d(r.abserr, 32);
-            fb2 = readlane_d(r.resabs, 32); fb3 = readlane_d(r.resasc, 32);
-            finished = qag_after_first(q, st, lane, a0, b0, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
-                                       readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
-            phase = 1;
+        int status = QAG_SUCCESS;
+        double result = 0., abserr = 0.;
+        double f_res, f_err, f_abs, f_asc;       // first-rule sums handed to the code after the first application
+        bool first_pending = false;
+        if (mode == M_FIRST) {
+            if (lane == 32) { lp->fb[0] = r.result; lp->fb[1] = r.abserr; lp->fb[2] = r.resabs; lp->fb[3] = r.resasc; }
+            f_res = r.result; f_err = r.abserr; f_abs = r.resabs; f_asc = r.resasc;     // lane 0 holds integral 0's
+            first_pending = true;
+            finished = false;
         } else {
             RIM_PROF_T(t_ab);
-            finished = qag_after_bisect(q, st, lane,
-                                        readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
-                                        readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+            // child 1 = this lane's own sums (right in lane 0), child 2 = lane 32's
+            const double area2 = readlane_d(r.result, 32), error2 = readlane_d(r.abserr, 32);
+            const double area1 = r.result, error1 = r.abserr;
+            const IEntry en = ist_entry(st, imax);
+            const double a_i = en.a, b_i = en.b, r_i = en.r, e_i = en.e;
+            const double area12 = area1 + area2;
+            const double error12 = error1 + error2;
+            const double errsum = lp->errsum + (error12 - e_i);
+            const double area = lp->area + (area12 - r_i);
+            {
+                // resasc != error for both children: each half-wave compares its own pair
+                const unsigned long long ne = wv_ballot(r.resasc != r.abserr);
+                if ((ne & 1ull) && ((ne >> 32) & 1ull)) {
+                    const double delta = r_i - area12;
+                    if (lane0_and(rim_fabs(delta) <= 1.0e-5 * rim_fabs(area12), error12 >= 0.99 * e_i)) rt1++;
+                    if (iteration >= 10 && lane0(error12 > e_i)) rt2++;
+                }
+            }
+            const double tolerance = (epsabs == 0.) ? epsrel * rim_fabs(area)          // = rim_max(0, x) for x >= 0 or NaN
+                                                    : rim_max(epsabs, epsrel * rim_fabs(area));
+            const bool more = lane0(errsum > tolerance);
+            int error_type = 0;
+            if (more) {
+                if (rt1 >= 6 || rt2 >= 20) error_type = 2;
+                const double mid = 0.5 * (a_i + b_i);
+                const double tmp = (1 + 100 * RIM_DBL_EPSILON) * (rim_fabs(mid) + 1000 * RIM_DBL_MIN);
+                if (lane0_and(rim_fabs(a_i) <= tmp, rim_fabs(b_i) <= tmp)) error_type = 3;
+            }
+            // update(): the child with the larger error keeps the parent's slot; lanes 0 and 32 file their own child
+            const bool c2gt = lane0(error2 > error1);
+            const bool overflow = size >= istore_capacity(st);
+            wv_sync();               // every lane has read the parent's entry
+            if (!overflow) {
+                if ((lane & 31) == 0) {
+                    const bool keep = (g.half != 0) == c2gt;
+                    const int slot = keep ? imax : size;
+                    const int stamp = 2 * iteration + (keep ? 0 : 1);
+                    if (slot < st.cap) {
+                        st.a[slot] = la; st.b[slot] = lb; st.r[slot] = r.result; st.e[slot] = r.abserr;
+                        st.stamp[slot] = stamp;
+                    } else {         // beyond the LDS part: the wave's spill region in global memory
+                        const int j = slot - st.cap;
+                        st.g[j] = la; st.g[st.gcap + j] = lb; st.g[2 * st.gcap + j] = r.result; st.g[3 * st.gcap + j] = r.abserr;
+                        ((int *) (st.g + 4 * st.gcap))[j] = stamp;
+                    }
+                }
+                size++;
+            }
+            iteration++;
+            if (lane == 0) { lp->area = area; lp->errsum = errsum; }
+            finished = !(!overflow && iteration < limit && !error_type && more);
+            if (finished) {
+                wv_sync();
+                double sum = 0;
+                if (size <= st.cap) { for (int k = 0; k < size; k++) sum += st.r[k]; }
+                else { for (int k = 0; k < size; k++) sum += ist_r(st, k); }
+                result = sum;
+                abserr = errsum;
+                if (lane0(errsum <= tolerance)) status = QAG_SUCCESS;      // (not "!more": a NaN error sum is a failure)
+                else if (overflow) status = QAG_ESTORE;
+                else if (error_type == 2) status = QAG_EROUND;
+                else if (error_type == 3) status = QAG_ESING;
+                else if (iteration == limit) status = QAG_EMAXITER;
+                else status = QAG_EFAILED;
+            }
             RIM_PROF_ADD(12, t_ab);
         }
-        if (!finished) continue;
 
-        for (;;) {                   // integral `cur` is complete
+        for (;;) {
+            if (first_pending) {
+                // qag_after_first on the first-rule sums in f_* (decisions from lane 0's values)
+                first_pending = false;
+                const double fa = cur ? a1 : a0, fb = cur ? b1 : b0;
+                if (epsabs <= 0 && (epsrel < 50 * RIM_DBL_EPSILON || epsrel < 0.5e-28)) {
+                    status = QAG_EBADTOL; result = 0.; abserr = 0.; size = 0;
+                    finished = true;
+                } else {
+                    wv_sync();
+                    if (lane == 0) {
+                        st.a[0] = fa; st.b[0] = fb; st.r[0] = f_res; st.e[0] = f_err; st.stamp[0] = 0;
+                        lp->area = f_res; lp->errsum = f_err;
+                    }
+                    size = 1;
+                    const double tolerance = rim_max(epsabs, epsrel * rim_fabs(f_res));
+                    const double round_off = 50 * RIM_DBL_EPSILON * f_abs;
+                    result = f_res;
+                    abserr = f_err;
+                    finished = true;
+                    if (lane0_and(f_err <= round_off, f_err > tolerance)) status = QAG_EROUND;
+                    else if (lane0_and(f_err <= tolerance, f_err != f_asc) || lane0(f_err == 0.0)) status = QAG_SUCCESS;
+                    else if (limit == 1) status = QAG_EMAXITER;
+                    else {
+                        finished = false;
+                        iteration = 1; rt1 = 0; rt2 = 0; imax = 0;
+                        mode = M_LEAN;
+                    }
+                }
+            }
+            if (!finished) break;
+            // integral `cur` is complete
             RIM_HIT(22);
-            if (lane == 0) park->ctr.inner_qags += 1;
-            if (cur == 0) { r0 = uni(q.result); qs0 = uni(q.status); } else { r1 = uni(q.result); qs1 = uni(q.status); }
-            if (abserr_out) abserr_out[cur] = q.abserr;
-            if (size_out) size_out[cur] = q.size;
-            if (cur != 0 || !have1) return;
+            if (cur == 0) { r0 = readlane_d(result, 0); qs0 = status; } else { r1 = readlane_d(result, 0); qs1 = status; }
+            if (abserr_out) abserr_out[cur] = readlane_d(abserr, 0);
+            if (size_out) size_out[cur] = size;
+            if (cur != 0 || !have1) {
+                if (lane == 0) {
+                    park->ctr.samples += n_samp;
+                    park->ctr.steps += n_pass;
+                    park->ctr.inner_qags += have1 ? 2 : 1;
+                    if (park->hb) {
+                        hb_store(park->hb + 3, park->ctr.steps);
+                        hb_store(park->hb + 4, (unsigned long long) iteration);
+                    }
+                }
+                return;
+            }
             cur = 1;                 // integral 1 continues from its parked first-rule result
-            qag_begin(q, epsabs, epsrel, limit);
-            if (!qag_after_first(q, st, lane, a1, b1, fb0, fb1, fb2, fb3)) break;
+            wv_sync();
+            f_res = lp->fb[0]; f_err = lp->fb[1]; f_abs = lp->fb[2]; f_asc = lp->fb[3];
+            first_pending = true;
+            finished = false;
         }
     }
 }
