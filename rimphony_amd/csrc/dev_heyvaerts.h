@@ -33,7 +33,7 @@ RIM_DEV double gamma_real(double z)
 {
     double prod = 1., w = z;
     int guard = 0;
-    while (w < 16. && guard < 64) { prod = prod * w; w = w + 1.; guard++; }
+    while (w < 16. && guard < 64) { RIM_HIT(24); prod = prod * w; w = w + 1.; guard++; }
     return rim_exp(rim_lgamma_stirling(w)) / prod;
 }
 
@@ -43,6 +43,7 @@ RIM_DEV double ascending_series(double nu, double q, double sign)
     for (int k = 1; k <= 500; k++) {
         // q = (x/2)^2 and k (k + nu) are normal numbers of moderate size (a negative order is never an exact
         // integer here: bessel_ynu perturbs those) -> the bare division is exact (detmath.h)
+        RIM_HIT(30);
         term = term * rim_div_moderate(sign * q, k * (k + nu));
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
@@ -71,6 +72,7 @@ RIM_DEV double ascending_series_tab(const double *row, double q, double sign)
 {
     double term = 1., sum = 1.;
     for (int k = 1; k <= RIM_SERIES_TERMS; k++) {
+        RIM_HIT(31);
         term = term * rim_div_by(sign * q, row[2 * k], row[2 * k + 1]);
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
@@ -106,6 +108,7 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
         nu_y[w] = nu;
         rim_sincos(RIM_PI * nu, &sn[w], &cs[w]);
     }
+    RIM_HIT(28);
     // jobs: 0 J(sigma), 1 J(sigma-1), 2 J(-nu_y0), 3 J(-nu_y1), 4 J(nu_y0) if perturbed, 5 J(nu_y1) if perturbed
     // (the six prefactors (x/2)^nu start from one double-double log of x/2)
     const double h = 0.5 * x, hsq = h * h;
@@ -123,7 +126,7 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
         else if (k < 4) { nu = -nu_y[w]; need = w == 0 || want_ym1; }
         else { nu = nu_y[w]; need = (w == 0 || want_ym1) && nu_y[w] != sigma - (double) w; }
         double v = 0.;
-        if (need) v = rim_pow_from_log(lh, ll, nu) / gamma_real(nu + 1.) * ascending_series(nu, hsq, -1.);   // = bessel_jnu(nu, x)
+        if (need) { RIM_HIT(29); v = rim_pow_from_log(lh, ll, nu) / gamma_real(nu + 1.) * ascending_series(nu, hsq, -1.); }   // = bessel_jnu(nu, x)
         r[k] = v;
     }
     *js = r[0];
@@ -167,6 +170,7 @@ RIM_DEV HeyConsts hey_consts(const double *series_tab)
 // calls, with the double-double log of x/2 that the four powers (x/2)^nu start from taken once.
 RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
 {
+    RIM_HIT(27);
     const double h = 0.5 * x;
     const double hsq = h * h;
     double ll;
@@ -316,12 +320,14 @@ template <int KIND>
 RIM_DEV double hey_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, bool qr, double fixed, double v)
 {
     if (qr) {
+        RIM_HIT(26);
         RIM_PROF_T(t_qr);
         const HeyCoord c = fill_coord_vars(pt, fixed, v);
         const double r = pt.stokes == STOKES_Q ? h_qr_element<KIND>(pt, d, hc, c) : f_qr_element<KIND>(pt, d, hc, c);
         RIM_PROF_ADD(19, t_qr);
         return r;
     }
+    RIM_HIT(25);
     RIM_PROF_T(t_nr);
     const HeyCoord c = fill_coord_vars(pt, v, fixed);
     const double r = pt.stokes == STOKES_Q ? h_nr_element<KIND>(pt, d, c) : f_nr_element<KIND>(pt, d, c);

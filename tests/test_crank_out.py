@@ -47,15 +47,68 @@ def test_driver_writes_reference_format(tmp_path, oracle):
     assert len(lines) == 8 and lines[6] == crank_out.HEADER_PITCHYPL
 
 
+def _redraw(kind_name, ranges, count, block, seed):
+    """The parameter columns crank_out.run draws for these arguments (same generator, same order)."""
+    rng = np.random.default_rng(seed)
+    logs = [True, False, False, False] if kind_name == "pitchypl" else [True, False, False, True, False]
+    samplers = [crank_out.Sampler(lg, ranges[2 * i], ranges[2 * i + 1], rng) for i, lg in enumerate(logs)]
+    blocks, written = [], 0
+    while written < count:
+        n = min(block, count - written)
+        blocks.append([smp.get(n) for smp in samplers])
+        written += n
+    return [np.concatenate([b[j] for b in blocks]) for j in range(len(logs))]
+
+
 @pytest.mark.gpu
-def test_driver_on_gpu(tmp_path, gpu_ctx):
-    from rimphony_amd import api
+@pytest.mark.parametrize("kind_name", ["pitchypl", "pitchykappa"])
+def test_driver_on_gpu_every_value_is_the_oracles(tmp_path, gpu_ctx, oracle, kind_name):
+    """The TSV the GPU driver writes, value by value: the parameter columns are the seeded draws, the eight result
+    columns are the ORACLE's bits for those parameters (printed with 17 significant digits, which round-trips a
+    double), the time column is positive and sums to the kernels' time (examples/crank-out-pitchypl.rs:157-195,
+    crank-out-pitchykappa.rs:184-217).  Also with two contexts sharing the block (--gpus path): identical rows."""
+    import oracle_bind
+    from rimphony_amd import api, workload
+    ranges = ([1.0, 50.0, 0.3, 1.3, 2.0, 3.5, 0.0, 2.0] if kind_name == "pitchypl"
+              else [1.0, 50.0, 0.3, 1.3, 2.0, 4.0, 3.0, 10.0, 0.0, 2.0])
     out = tmp_path / "k.txt"
-    crank_out.run("pitchykappa", str(out), [1.0, 50.0, 0.3, 1.3, 2.0, 4.0, 3.0, 10.0, 0.0, 2.0], count=6, block=4, seed=3,
-                  compute=lambda kind, s, th, params: gpu_ctx.compute_batch(kind, s, th, params, api.SLOTS_ALL))
+    crank_out.run(kind_name, str(out), ranges, count=10, block=4, seed=3, compute=crank_out.gpu_compute([gpu_ctx]))
     lines = out.read_text().strip().split("\n")
-    assert lines[0] == crank_out.HEADER_PITCHYKAPPA and len(lines) == 7
-    assert all(len(ln.split("\t")) == 14 for ln in lines[1:])
+    header = crank_out.HEADER_PITCHYPL if kind_name == "pitchypl" else crank_out.HEADER_PITCHYKAPPA
+    assert lines[0] == header and len(lines) == 11
+    npar = 4 if kind_name == "pitchypl" else 5
+    rows = np.array([[float(x) if x != "NaN" else np.nan for x in ln.split("\t")] for ln in lines[1:]])
+    assert rows.shape == (10, npar + 9)
+    cols = _redraw(kind_name, ranges, 10, 4, 3)
+    for j in range(npar):
+        assert (rows[:, j] == cols[j]).all()
+    n = 10
+    if kind_name == "pitchypl":
+        kind, params = workload.PITCHY_PL, [cols[2], cols[3], np.ones(n), 1e12 * np.ones(n), 1e10 * np.ones(n)]
+    else:
+        kind, params = workload.PITCHY_KAPPA, [cols[2], cols[3], cols[4], 1e10 * np.ones(n)]
+    ref = oracle_bind.batch(oracle, kind, cols[0], cols[1], params, 0xFF, nthreads=16)
+    got = rows[:, npar + 1:]
+    same = (got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), np.argwhere(~same)
+    assert (rows[:, npar] > 0).all()
+    # the same run sharded over two contexts (second one on the same device): identical parameter and result columns
+    c2 = api.Context(0)
+    try:
+        out2 = tmp_path / "k2.txt"
+        crank_out.run(kind_name, str(out2), ranges, count=10, block=4, seed=3, compute=crank_out.gpu_compute([gpu_ctx, c2]))
+        lines2 = out2.read_text().strip().split("\n")
+        for a, b in zip(lines[1:], lines2[1:]):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert fa[:npar] == fb[:npar] and fa[npar + 1:] == fb[npar + 1:]
+    finally:
+        c2.close()
+
+
+def test_row_times_apportion_the_kernel_times():
+    work = np.array([[10, 0, 0, 0, 0, 0, 5, 0], [30, 0, 0, 0, 0, 0, 15, 0]], dtype=np.int64)
+    ms = crank_out.row_times_ms(work, 8.0, 2.0)
+    assert np.allclose(ms, [2.0 + 0.5, 6.0 + 1.5]) and abs(ms.sum() - 10.0) < 1e-12
 
 
 def test_demo_powerlaw_and_all8_text():

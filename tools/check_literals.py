@@ -55,7 +55,7 @@ def run_chain(body, env):
     e = {}
     e.update({"R": sp.Rational, "rim_fma": lambda a, b, c: a * b + c, "rim_fma_k": lambda a, b, c: a * b + c,
               "fma": lambda a, b, c: a * b + c, "FMA": lambda a, b, c: a * b + c,
-              "rim_div_by": lambda a, b, binv: a / b, "rim_div_moderate": lambda a, b: a / b,
+              "rim_div_by": lambda a, b, binv: a / b, "rim_div_moderate": lambda a, b: a / b, "rim_head": lambda a: a,
               "rim_sqrt": sp.sqrt, "m_sqrt": sp.sqrt, "sqrt": sp.sqrt,
               "rim_pow15": lambda x: x ** sp.Rational(3, 2), "rim_pow25": lambda x: x ** sp.Rational(5, 2),
               "m_pow15": lambda x: x ** sp.Rational(3, 2), "m_pow25": lambda x: x ** sp.Rational(5, 2)})
@@ -64,6 +64,7 @@ def run_chain(body, env):
     body = re.sub(r"//[^\n]*", "", body)
     for stmt in body.split(";"):
         stmt = stmt.strip().replace("\n", " ")
+        stmt = re.split(r"[{}]", stmt)[-1].strip()          # drop a function head or a closing brace in front
         if not stmt or "=" not in stmt:
             continue
         stmt = re.sub(r"^(const\s+)?double\s+", "", stmt)
@@ -99,7 +100,9 @@ def main():
         print("reference not mounted at %s: nothing to check" % REF)
         return 0
     bc = open(os.path.join(REF, "leung-bessel", "src", "bessel.c")).read()
-    dev = open(os.path.join(ROOT, "rimphony_amd", "csrc", "dev_bessel.h")).read()
+    # (RIMPHONY_CHECK_DEV_BESSEL: another file in place of dev_bessel.h -- the test suite feeds a mutated copy to
+    # show that a flipped sign is caught)
+    dev = open(os.environ.get("RIMPHONY_CHECK_DEV_BESSEL") or os.path.join(ROOT, "rimphony_amd", "csrc", "dev_bessel.h")).read()
     orc = open(os.path.join(ROOT, "oracle", "rimo_bessel.c")).read()
     t1, t2, U, eps, Z, ninv, n, x, z, ez, t3, t4, t10 = sp.symbols("t1 t2 U eps Z ninv n x z ez t3 t4 t10")
     At = sp.symbols("At0:16")
@@ -274,7 +277,18 @@ def main():
         body = rust_fn(name)
         e = dict(renv)
         e["R"] = sp.Rational
-        stmts = re.split(r";\s*\n", body)
+        stmts, depth, cur = [], 0, ""
+        for ch in body:                   # split on ';' outside braces (the if / else blocks hold statements too)
+            if ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+            if ch == ";" and depth == 0:
+                stmts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        stmts.append(cur)
         last = None
         for st in stmts:
             st = st.strip().replace("\n", " ")

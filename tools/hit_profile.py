@@ -14,7 +14,8 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2_powerlaw_jI_aI"
 ctx = api.Context(0)
 dev = torch.device("cuda", 0)
 kind, mask, s, th, params = workload.make_batch(cfg, n, start=0)
-mask &= 0x3f
+faraday = len(sys.argv) > 3 and sys.argv[3] == "faraday"
+mask = 0xc0 if faraday else mask & 0x3f
 ds, dth, dp = torch.from_numpy(s).to(dev), torch.from_numpy(th).to(dev), [torch.from_numpy(p).to(dev) for p in params]
 ctx.compute_batch_device(kind, ds, dth, dp, mask)
 ctx.debug_counters()                      # reset after the warm-up launch
@@ -27,6 +28,13 @@ names = {0: "integrand pass", 1: "  joint first application", 2: "qag_pick argma
          14: "beta < 0.1", 15: "beta >= 0.1", 16: "miller recurrence", 17: "select: x > n side", 18: "select: blend zone",
          19: "calc_f inside limits", 20: "calc_f_derivatives inside limits", 21: "request setup (pair)", 22: "integral complete",
          24: "emission f_term", 25: "absorption f_term"}
-print("kernel ms %.1f  samples %d passes %d  hits[0] %d" % (ctx.last_symphony_ms(), w["samples"], w["passes"], c[0]))
+if faraday:
+    names = {0: "integrand pass", 1: "  joint first application", 2: "qag_pick argmax (size > 2)", 22: "integral complete",
+             25: "non-resonant element pass", 26: "quasi-resonant element pass", 27: "  I_{+-1/3,2/3} branch executed (bessel_i_g4)",
+             28: "  J/Y branch executed (bessel_jy_set)", 29: "    J/Y jobs run (of 6 per execution)", 24: "    gamma_real shift-up iterations",
+             30: "    real-order series term iterations", 31: "  fixed-order (table) series term iterations"}
+    print("faraday kernel ms %.1f  samples %d passes %d  hits[0] %d" % (ctx.last_faraday_ms(), w["faraday_samples"], w["faraday_passes"], c[0]))
+else:
+    print("kernel ms %.1f  samples %d passes %d  hits[0] %d" % (ctx.last_symphony_ms(), w["samples"], w["passes"], c[0]))
 for k in sorted(names):
     print("%-40s %12d   %7.4f per pass" % (names[k], c[k], c[k] / max(c[0], 1)))
