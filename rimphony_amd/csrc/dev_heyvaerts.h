@@ -68,12 +68,32 @@ RIM_DEV void hey_series_table_entry(int j, int k, double *entry)
     entry[1] = 1. / b;
 }
 
-RIM_DEV double ascending_series_tab(const double *row, double q, double sign)
+// The first RIM_SERIES_LDS entries of each order's row are also kept in the wave's LDS (lrow; layout [0 .. RIM_SERIES_LDS + 1]
+// pairs, entry 0 unused, the last one padding for the one-term-ahead read): a term of the series is 8 vector instructions,
+// and one global load per term with a full wait in between left the wave stalled for most of each iteration (the
+// Faraday kernel was 75 % VALU-busy).  LDS reads are prefetched one term ahead.  Series longer than that (rare: g
+// close to 10) continue from the global table.  Host builds pass the same array for both.
+#define RIM_SERIES_LDS 20
+#define RIM_SERIES_LDS_ROW (2 * (RIM_SERIES_LDS + 2))
+
+RIM_DEV double ascending_series_tab(const double *lrow, const double *row, double q, double sign)
 {
     double term = 1., sum = 1.;
-    for (int k = 1; k <= RIM_SERIES_TERMS; k++) {
+    const double sq = sign * q;
+    double b = lrow[2], binv = lrow[3];
+    int k = 1;
+    for (; k <= RIM_SERIES_LDS; k++) {
         RIM_HIT(31);
-        term = term * rim_div_by(sign * q, row[2 * k], row[2 * k + 1]);
+        const double bn = lrow[2 * k + 2], bninv = lrow[2 * k + 3];      // next term's divisor, in flight during this term
+        term = term * rim_div_by(sq, b, binv);
+        sum = sum + term;
+        if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) return sum;
+        b = bn;
+        binv = bninv;
+    }
+    for (; k <= RIM_SERIES_TERMS; k++) {
+        RIM_HIT(31);
+        term = term * rim_div_by(sq, row[2 * k], row[2 * k + 1]);
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
     }
@@ -150,15 +170,30 @@ inline const double *hey_series_table_host()
     }
     return tab;
 }
+inline const double *hey_series_lds_table_host()
+{
+    static double ltab[4 * RIM_SERIES_LDS_ROW];
+    static bool ready = false;
+    if (!ready) {
+        const double *tab = hey_series_table_host();
+        for (int j = 0; j < 4; j++)
+            for (int i = 0; i < RIM_SERIES_LDS_ROW; i++) ltab[j * RIM_SERIES_LDS_ROW + i] = tab[j * RIM_SERIES_ROW + i];
+        ready = true;
+    }
+    return ltab;
+}
 #endif
 
 // Per-task constants: Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3, and the series divisor table.
-struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; const double *tab; };
+struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; const double *tab; const double *ltab; };
 
-RIM_DEV HeyConsts hey_consts(const double *series_tab)
+// series_tab: the global table; lds_tab: the wave's LDS copy of its head ([4][RIM_SERIES_LDS_ROW], filled by
+// hey_series_lds_fill) or, on the host, a table with that layout
+RIM_DEV HeyConsts hey_consts(const double *series_tab, const double *lds_tab)
 {
     HeyConsts c;
     c.tab = series_tab;
+    c.ltab = lds_tab;
     c.g_p23 = gamma_real(2. / 3. + 1.);
     c.g_m23 = gamma_real(-2. / 3. + 1.);
     c.g_p13 = gamma_real(1. / 3. + 1.);
@@ -180,7 +215,8 @@ RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
 #pragma nounroll
 #endif
     for (int j = 0; j < 4; j++)
-        out[j] = rim_pow_from_log(lh, ll, hey_series_order(j)) / gam[j] * ascending_series_tab(hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
+        out[j] = rim_pow_from_log(lh, ll, hey_series_order(j)) / gam[j]
+            * ascending_series_tab(hc.ltab + j * RIM_SERIES_LDS_ROW, hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
 }
 
 // Observer data of one Faraday coefficient (wave-uniform)

@@ -141,7 +141,7 @@ __device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, co
 // (heyvaerts.rs:224-226), and the other one then runs alone.
 template <int KIND>
 __device__ __forceinline__ void hey_eval_pair(const HeyPoint &pt, const DistParams &dist, const HeyConsts &hc,
-                                              const GKLane &g, const IStore &inner, QagPark *qpark,
+                                              const GKLane &g, const IStore &inner, QagParkBase *qpark,
                                               double u0, int qr0, double u1, int qr1, bool have1,
                                               double &val0, int &st0, double &val1, int &st1)
 {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void hey_eval_pair(const HeyPoint &pt, const DistPara
 
 template <int KIND>
 __device__ __forceinline__ double hey_eval_request(const HeyPoint &pt, const DistParams &dist, const HeyConsts &hc,
-                                                   const GKLane &g, const IStore &inner, QagPark *qpark,
+                                                   const GKLane &g, const IStore &inner, QagParkBase *qpark,
                                                    double u, int qr_flag, int &st)
 {
     double v0, v1;
@@ -348,7 +348,7 @@ __device__ __forceinline__ double hey_result(const HeyTask &T, int &status_out)
 template <int KIND>
 __device__ __forceinline__ double heyvaerts_coefficient(const HeyPoint &pt, const DistParams &dist, const HeyConsts &hc,
                                                         const GKLane &g, const IStore &inner, const IStore &outer,
-                                                        HeyTask *park, QagPark *qpark, int &status_out)
+                                                        HeyTask *park, QagParkBase *qpark, int &status_out)
 {
     const int lane = g.lane;
     HeyTask T;

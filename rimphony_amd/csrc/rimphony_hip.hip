@@ -297,8 +297,9 @@ template <int KIND>
 struct SymphonyProblem {
     struct Ctx { SymPoint pt; DistParams d; };
     typedef TaskState Task;
-    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0 };
-    static __device__ __forceinline__ void init(const SymArgs &, Ctx &) {}
+    typedef QagPark Park;
+    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0, EXTRA_LDS_DOUBLES = 1 };
+    static __device__ __forceinline__ void init(const SymArgs &, Ctx &, double *) {}
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     { load_context<KIND>(a, i, slot, c.pt, c.d, norm); }
     static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { sym_begin(c.pt, T); }
@@ -307,7 +308,7 @@ struct SymphonyProblem {
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
     { sym_post(c.pt, g, outer, T, B); }
     // one or two requests ((x1, tag1) only if have1): two gamma-integrals share their first rule application
-    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, Park *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
     { sym_eval_pair<KIND>(c.pt, c.d, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
@@ -321,10 +322,17 @@ template <int KIND>
 struct HeyvaertsProblem {
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
     typedef HeyTask Task;
-    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62 };
-    static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c)
+    typedef QagParkBase Park;
+    // 5 waves per SIMD = 20 workgroups per CU leave 8 KB of LDS per wave: room for the head of the series divisor table
+    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 4 * RIM_SERIES_LDS_ROW };
+    static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
-        c.hc = hey_consts(a.series_tab);
+        for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64) {
+            const int j = i / RIM_SERIES_LDS_ROW, r = i % RIM_SERIES_LDS_ROW;
+            extra_lds[i] = a.series_tab[j * RIM_SERIES_ROW + r];
+        }
+        __syncthreads();
+        c.hc = hey_consts(a.series_tab, extra_lds);
         c.hc.g_p23 = uni(c.hc.g_p23); c.hc.g_m23 = uni(c.hc.g_m23); c.hc.g_p13 = uni(c.hc.g_p13); c.hc.g_m13 = uni(c.hc.g_m13);
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
@@ -351,7 +359,7 @@ struct HeyvaertsProblem {
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
     { hey_post(c.pt, g, outer, T, B); }
-    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, QagPark *qp,
+    static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, Park *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
     { hey_eval_pair<KIND>(c.pt, c.d, c.hc, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     double *spill = a.spill + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
     const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
     const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
-    __shared__ QagPark s_qpark;
+    __shared__ typename P::Park s_qpark;
+    __shared__ double s_extra[P::EXTRA_LDS_DOUBLES];
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
 
     AssistSlot *const my = a.board + blockIdx.x;
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) a.nslots;
     typename P::Ctx cx;                    // context of the requests being evaluated (own task or a helped one)
-    P::init(a, cx);
+    P::init(a, cx, s_extra);
     unsigned long long *const queue = a.queue + P::QUEUE;
     // The own task's state lives in LDS (s_park) between the three places that touch it, so that it
     // never occupies registers while the integrand runs.
@@ -1204,6 +1213,18 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
         *resident = nb < 4 * (int) P::WAVES ? nb : 4 * (int) P::WAVES;
     }
     int resident_per_cu = *resident;
+    {   // The occupancy query has been seen to count one workgroup too many when the grid is LDS-bound to the last
+        // granule (a grid with non-resident waves does not fail, it stalls: every helper's 2 s idle bound).  Re-derive
+        // the LDS limit here with the 512-byte allocation granule and one granule of slack.
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(coop_kernel<P>)) == hipSuccess) {
+            const size_t lds = ((fa.sharedSizeBytes + RIM_DYN_LDS + 511) / 512) * 512;
+            if (lds > 0) {
+                const int by_lds = (int) ((160 * 1024 - 512) / lds);
+                if (by_lds >= 1 && by_lds < resident_per_cu) resident_per_cu = by_lds;
+            }
+        }
+    }
     if (c->shared_mode) resident_per_cu = resident_per_cu >= 8 ? resident_per_cu / 4 : 2;   // leave room for the other tenant
     const unsigned grid = persistent_grid(c, want_waves, resident_per_cu);
     int rc = ensure_spill(c, grid);

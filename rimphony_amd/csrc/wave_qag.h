@@ -463,12 +463,16 @@ struct LeanPark {
     double fb[4];             // result, abserr, resabs, resasc of integral 1's first rule application
 };
 
-struct QagPark {
+struct QagParkBase {
     LeanPark lean;
-    QagState q;
-    LeungOrder ord[4];        // order records (n, n + 1) of the one or two gamma-integrals in flight (SymOrder)
+    QagState q;               // wave_qag (the single-integral form) parks its state here
     WaveCounters ctr;
     unsigned long long *hb;   // optional heartbeat words in host-mapped memory (diagnostics), else null
+};
+// ... plus, for the Symphony integrand, the order records (n, n + 1) of the one or two gamma-integrals in flight
+// (SymOrder); the Heyvaerts kernel spends that LDS on the head of its series divisor table instead
+struct QagPark : QagParkBase {
+    LeungOrder ord[4];
 };
 
 // Diagnostics: make a word visible to the host while the kernel is still running.
@@ -486,7 +490,7 @@ __device__ __forceinline__ void hb_store(unsigned long long *p, unsigned long lo
 // must return 0 for inactive lanes.
 template <class F>
 __device__ __forceinline__ void wave_qag(F &f, const GKLane &g, const IStore &st, double a, double b,
-                                double epsabs, double epsrel, int limit, QagState &q, QagPark *park)
+                                double epsabs, double epsrel, int limit, QagState &q, QagParkBase *park)
 {
     qag_begin(q, epsabs, epsrel, limit);
     bool first = true;
@@ -652,7 +656,7 @@ __device__ __forceinline__ IEntry ist_entry(const IStore &st, int i)
 template <class F>
 __device__ __forceinline__ void wave_qag_pair(F &f, const GKLane &g, const IStore &st,
                                               double a0, double b0, double a1, double b1, bool have1, bool flip,
-                                              double epsabs, double epsrel, int limit, QagPark *park,
+                                              double epsabs, double epsrel, int limit, QagParkBase *park,
                                               double &r0, int &qs0, double &r1, int &qs1,
                                               double *abserr_out = nullptr, int *size_out = nullptr)   // [2] each, optional
 {

@@ -50,7 +50,7 @@ static void lane_body(EmuTask *t)
         HeyPoint hp;
         hp.s = pt.s; hp.sin_th = pt.sin_th; hp.cos_th = pt.cos_th;
         hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = t->stokes;
-        const HeyConsts hc = hey_consts(hey_series_table_host());
+        const HeyConsts hc = hey_consts(hey_series_table_host(), hey_series_lds_table_host());
         val = heyvaerts_coefficient<KIND>(hp, d, hc, g, inner, outer, &s_hpark, &s_qpark, st);
     } else {
         val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
