@@ -85,8 +85,13 @@ int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unkno
 #define RIMPHONY_EBUSY     -5   /* RIMPHONY_EXCLUSIVE=1 and another context already has the device */
 #define RIMPHONY_ENOTSUP   -6   /* e.g. a `precision` this build does not implement */
 
-/* `precision` of the _ex / _multi entry points.  F64 is the reference's arithmetic and the only one
- * implemented; F32_INTEGRAND (BASELINE configs[4]: fp32 integrand, fp64 Kahan accumulation) is reserved and returns
+/* `precision` of the _ex / _multi entry points.  F64 is the reference's arithmetic (bit-identical to the
+ * oracle).  F32_INTEGRAND (BASELINE configs[4]) evaluates the bodies of the elementary functions of the Symphony
+ * integrand -- the exponential of a reduced argument, the logarithm of a mantissa, the Debye cube root -- in single
+ * precision on the hardware transcendental unit, with every difference, every product with the harmonic number and
+ * every quadrature sum in fp64; it applies to the six Symphony slots (the Faraday pair is always fp64) and carries
+ * no parity claim: ~1e-8 median, ~1e-6 p99 relative difference from F64, and a noisier integrand for the adaptive
+ * quadrature (DESIGN.md section 5 has the measured distributions and where it is slower than F64).  Any other value:
  * RIMPHONY_ENOTSUP. */
 #define RIMPHONY_PRECISION_F64            0
 #define RIMPHONY_PRECISION_F32_INTEGRAND  1

@@ -58,6 +58,9 @@ SLOTS = [
 ]
 SLOTS_ALL = 0xFF
 SLOTS_SYMPHONY = 0x3F
+# `precision` of the batch entry points (include/rimphony_hip.h)
+PRECISION_F64 = 0               # the reference's arithmetic; bit-identical to the oracle
+PRECISION_F32_INTEGRAND = 1     # fp32-core elementary functions in the Symphony integrand; no parity claim
 
 
 def slot_of(coeff, stokes):
@@ -115,7 +118,8 @@ class Context:
         if not t.is_contiguous():
             raise ValueError("%s: not contiguous (pass t.contiguous())" % name)
 
-    def compute_batch_device(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False):
+    def compute_batch_device(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False,
+                             precision=PRECISION_F64):
         """s, theta: CUDA float64 tensors [n]; params: list of CUDA float64 tensors [n].
         Returns (out [n, 8] CUDA tensor, status [n, 8] int32 CUDA tensor or None) -- and, with want_work, a third
         element: [n, 8] int64 integrand samples spent per coefficient.  Asynchronous on the current stream."""
@@ -136,7 +140,7 @@ class Context:
         pp = (ctypes.c_void_p * len(params))(*[ctypes.c_void_p(p.data_ptr()) for p in params])
         capi.check(self.lib.rimphony_batch_compute_device_ex(
             self.handle, kind, n, ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(theta.data_ptr()), pp,
-            coeff_mask, 0, ctypes.c_void_p(out.data_ptr()),
+            coeff_mask, int(precision), ctypes.c_void_p(out.data_ptr()),
             ctypes.c_void_p(status.data_ptr()) if want_status else None,
             ctypes.c_void_p(work.data_ptr()) if want_work else None, self._stream()),
             "rimphony_batch_compute_device_ex")
@@ -144,11 +148,12 @@ class Context:
             return out, status, work
         return out, status
 
-    def compute_batch(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False):
+    def compute_batch(self, kind, s, theta, params, coeff_mask=SLOTS_ALL, want_status=False, want_work=False,
+                      precision=PRECISION_F64):
         """Host arrays in, numpy arrays out (synchronous)."""
         ds, dth = self._as_dev(s), self._as_dev(theta)
         dp = [self._as_dev(p) for p in params]
-        res = self.compute_batch_device(kind, ds, dth, dp, coeff_mask, want_status, want_work)
+        res = self.compute_batch_device(kind, ds, dth, dp, coeff_mask, want_status, want_work, precision)
         torch.cuda.synchronize(self._dev())
         ret = [res[0].cpu().numpy()]
         if want_status:

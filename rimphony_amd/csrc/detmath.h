@@ -595,4 +595,82 @@ RIM_FN void rim_sincos(double x, double *sn, double *cs)
     }
 }
 
+/* ---- fp32-core variants (RIMPHONY_PRECISION_F32_INTEGRAND; BASELINE.json configs[4]) --------------------
+ * The "fp32 integrand" variant keeps every difference and every product with a large factor in fp64 (the
+ * kinematics n - z, eps = (n - x) / n, gamma sin xi, the Meissel exponent n (log .. - (1 - Z))) and evaluates the
+ * BODIES of the elementary functions in single precision on the hardware transcendental unit: the exponential of a
+ * reduced argument, the logarithm of a mantissa.  Relative error ~1e-7 per call instead of ~1e-16; a quarter to a
+ * half of the instructions.  No bit-parity contract: the host forms use libm's exp2f / log2f. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RIM_EXP2F(x) __builtin_amdgcn_exp2f(x)
+#define RIM_LOG2F(x) __builtin_amdgcn_logf(x)
+#else
+#define RIM_EXP2F(x) __builtin_exp2f(x)
+#define RIM_LOG2F(x) __builtin_log2f(x)
+#endif
+
+/* exp(x): range reduction in fp64 (k = rint(x / ln 2), r = x - k ln 2 exactly as rim_exp does), 2^(r / ln 2) in
+ * fp32, scaling by 2^k in fp64: relative error ~1e-7 for every x, however large |x| */
+RIM_FN double rim_exp_f32core(double x)
+{
+    if (rim_isnan(x)) return x;
+    if (x > 709.782712893384) return RIM_INF;
+    if (x < -745.2) return 0.0;
+    const double kd = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = rim_fma(-kd, 6.93147180369123816490e-01, x);
+    r = rim_fma(-kd, 1.90821492927058770002e-10, r);
+    const float e = RIM_EXP2F((float) (r * 1.44269504088896338700e+00));
+    return rim_ldexp((double) e, (int) kd);
+}
+
+/* x^y for a positive normal finite x: log2 x = exponent (exact) + log2(mantissa) (fp32), y log2 x split into integer
+ * and fraction in fp64, 2^fraction in fp32.  Relative error ~ (1 + |y| |log2 x|) 1e-7. */
+RIM_FN double rim_pow_f32core(double x, double y)
+{
+    uint64_t u = rim_bits(x);
+    const int e = (int) (u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    const double l2 = (double) e + (double) RIM_LOG2F((float) rim_frombits(u));
+    const double p = y * l2;
+    if (rim_isnan(p)) return p;
+    if (p > 1024.0) return RIM_INF;
+    if (p < -1075.0) return 0.0;
+    const double kd = __builtin_rint(p);
+    const float f = RIM_EXP2F((float) (p - kd));
+    return rim_ldexp((double) f, (int) kd);
+}
+
+/* x^(1/3) for a positive normal finite x: the fp32-core power refined by one Newton step in fp64
+ * (y - (y^3 - x) / (3 y^2) with the quotient's reciprocal in fp32): relative error ~1e-13 */
+RIM_FN double rim_cbrt_f32core(double x)
+{
+    const double y = rim_pow_f32core(x, 1. / 3.);
+    const double y2 = y * y;
+    const float rc = 1.0f / (float) (3. * y2);
+    return rim_fma(-rim_fma(y2, y, -x), (double) rc, y);
+}
+
+/* The elementary functions of the integrand by precision variant (0: fp64, the reference's arithmetic; 1: fp32 core) */
+#if defined(__cplusplus)
+template <int PREC> struct RimMath {
+    RIM_FN double exp(double x) { return rim_exp(x); }
+    RIM_FN double exp_bounded(double x) { return rim_exp_bounded(x); }
+    RIM_FN double pow(double x, double y) { return rim_pow(x, y); }
+    RIM_FN double pow_normal(double x, double y) { return rim_pow_normal(x, y); }
+    RIM_FN double cbrt_normal(double x) { return rim_pow_normal(x, 1. / 3.); }      /* bessel.c:180 pow(x, 1./3.) */
+};
+template <> struct RimMath<1> {
+    RIM_FN double exp(double x) { return rim_exp_f32core(x); }
+    RIM_FN double exp_bounded(double x) { return rim_exp_f32core(x); }
+    /* sin_xi^k and friends: x may be 0 or the exponent 0 -- keep the general function's special cases */
+    RIM_FN double pow(double x, double y)
+    {
+        if (!(x > 2.3e-308) || !rim_isfinite(x) || y == 0.0 || !rim_isfinite(y)) return rim_pow(x, y);
+        return rim_pow_f32core(x, y);
+    }
+    RIM_FN double pow_normal(double x, double y) { return rim_pow_f32core(x, y); }
+    RIM_FN double cbrt_normal(double x) { return rim_cbrt_f32core(x); }
+};
+#endif
+
 #endif /* RIM_DETMATH_H */

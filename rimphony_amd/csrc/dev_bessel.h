@@ -39,8 +39,10 @@
 
 namespace rim {
 
+template <int PREC = 0>
 RIM_DEV double exp_factor(double f_factor, double f_exp)
 {
+    typedef RimMath<PREC> M;
     if (f_factor == 0.) return 0.;
     const double a = rim_fabs(f_exp);
     if (a < 1e-3) {
@@ -68,12 +70,12 @@ RIM_DEV double exp_factor(double f_factor, double f_exp)
         const double af = rim_fabs(f_factor);
         if ((af < 1. && f_exp > 0.) || (af > 1. && f_exp < 0.)) {
             const double sign_f = (f_factor < 0) ? -1. : 1.;
-            return sign_f * rim_exp(rim_log(af) + f_exp);
+            return sign_f * M::exp(rim_log(af) + f_exp);
         }
-        return f_factor * rim_exp(f_exp);
+        return f_factor * M::exp(f_exp);
     }
     RIM_HIT(13);
-    return f_factor * rim_exp_bounded(f_exp);      // 1e-3 <= |f_exp| <= 690 here (or NaN, which stays NaN)
+    return f_factor * M::exp_bounded(f_exp);      // 1e-3 <= |f_exp| <= 690 here (or NaN, which stays NaN)
 }
 
 // 10^t to single precision (relative error ~1e-6; only ever used behind a 1e-3 guard band, so the
@@ -130,6 +132,7 @@ RIM_DEV LeungOrder leung_order(double n)
 
 // Horner over the eight coefficient rows of the Meissel-first V_n sum
 // (Chishtie et al. 2005, as tabulated in bessel.c:108-118).
+template <int PREC = 0>
 RIM_DEV double meissel_first(const LeungOrder &o, double x)
 {
     RIM_HIT(6);
@@ -225,7 +228,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
         RIM_PROF_ADD(15, t_ml);
     }
     RIM_PROF_T(t_me);
-    const double mres = exp_factor(factor, exp_val);
+    const double mres = exp_factor<PREC>(factor, exp_val);
     RIM_PROF_ADD(16, t_me);
     return mres;
 }
@@ -300,6 +303,7 @@ RIM_DEV double debye_eps(double n, double x)
 // and the thirteen coefficient polynomials in x^(1/3) -- is shared, each coefficient being consumed by both
 // Horner recurrences as soon as it is formed (two accumulators live instead of thirteen hoisted coefficients).
 // Per order the operations and their order are those of debye_eps.
+template <int PREC = 0>
 RIM_DEV void debye_eps_pair(double n0, double n1, double x, double *r0, double *r1)
 {
     if (x > 1.e55) { *r0 = RIM_NAN; *r1 = RIM_NAN; return; }
@@ -307,7 +311,7 @@ RIM_DEV void debye_eps_pair(double n0, double n1, double x, double *r0, double *
 
     const double ez0 = x - n0, ez1 = x - n1;
     RIM_PROF_T(t_dp);
-    const double z = rim_pow_normal(x, 1. / 3.);      // x > 0: the Debye band lies next to x = n >= 30
+    const double z = RimMath<PREC>::cbrt_normal(x);   // x > 0: the Debye band lies next to x = n >= 30
     RIM_PROF_ADD(17, t_dp);
     const double t3 = z * z;
     const double t4 = x * z;

@@ -55,69 +55,72 @@ RIM_DEV void dist_prepare(DistParams &d, double norm)
 }
 
 // (1 + (gamma - 1) / (kappa width))^-(kappa + 1) of the pitchy-kappa distribution
+template <int PREC = 0>
 RIM_DEV double kappa_gamma_power(const DistParams &d, double gamma)
 {
     const double base = 1. + (gamma - 1.) * d.inv_kappa_width;
     const double y = -(d.par[0] + 1.);
-    if (rim_bits(d.par[4]) != 0) return rim_pow_normal(base, y);     // wave-uniform test
+    if (rim_bits(d.par[4]) != 0) return RimMath<PREC>::pow_normal(base, y);     // wave-uniform test
     return rim_pow(base, y);
 }
 
-template <int KIND>
+template <int KIND, int PREC = 0>
 RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
 {
+    typedef RimMath<PREC> M;
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
         RIM_HIT(19);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        return d.norm * rim_pow_normal(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
+        return d.norm * M::pow_normal(gamma, -d.par[0]) * M::exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
     } else if (KIND == DIST_THERMAL_JUETTNER) {
-        return d.norm * rim_exp(d.neg_inverse_t * gamma);
+        return d.norm * M::exp(d.neg_inverse_t * gamma);
     } else if (KIND == DIST_PITCHY_PL) {
         if (gamma < d.par[2] || gamma > d.par[3]) return 0.;
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
-        const double pa_term = rim_pow(sin_xi, d.par[1]);
+        const double pa_term = M::pow(sin_xi, d.par[1]);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = rim_pow_normal(gamma, -d.par[0]) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = M::pow_normal(gamma, -d.par[0]) * M::exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term / (gamma * gamma * beta);
     } else {
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
-        const double pa_term = rim_pow(sin_xi, d.par[2]);
-        const double gamma_term = kappa_gamma_power(d, gamma) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double pa_term = M::pow(sin_xi, d.par[2]);
+        const double gamma_term = kappa_gamma_power<PREC>(d, gamma) * M::exp(-gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term;
     }
 }
 
-template <int KIND>
+template <int KIND, int PREC = 0>
 RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi, double &dfdg, double &dfdcx)
 {
+    typedef RimMath<PREC> M;
     if (KIND == DIST_POWER_LAW) {
         if (gamma < d.par[1] || gamma > d.par[2]) { dfdg = 0.; dfdcx = 0.; return; }
         RIM_HIT(20);
         const double p_plus_1 = d.par[0] + 1.;
         const double g2_minus_1 = gamma * gamma - 1.;
-        dfdg = -d.norm * rim_pow_normal(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
-            rim_exp(-gamma * d.inv_gamma_cutoff) *
+        dfdg = -d.norm * M::pow_normal(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
+            M::exp(-gamma * d.inv_gamma_cutoff) *
             (p_plus_1 / gamma + gamma / g2_minus_1 + d.inv_gamma_cutoff);
         dfdcx = 0.;
     } else if (KIND == DIST_THERMAL_JUETTNER) {
-        dfdg = d.norm * rim_exp(d.neg_inverse_t * gamma) * d.neg_inverse_t;
+        dfdg = d.norm * M::exp(d.neg_inverse_t * gamma) * d.neg_inverse_t;
         dfdcx = 0.;
     } else if (KIND == DIST_PITCHY_PL) {
         if (gamma < d.par[2] || gamma > d.par[3]) { dfdg = 0.; dfdcx = 0.; return; }
         const double p = d.par[0], k = d.par[1];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
-        const double pa_term = rim_pow(sin_xi, k);
+        const double pa_term = M::pow(sin_xi, k);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = rim_pow_normal(gamma, -p) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = M::pow_normal(gamma, -p) * M::exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
         dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
     } else {
         const double kappa = d.par[0], width = d.par[1], k = d.par[2];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
-        const double pa_term = rim_pow(sin_xi, k);
-        const double gamma_term = kappa_gamma_power(d, gamma) * rim_exp(-gamma * d.inv_gamma_cutoff);
+        const double pa_term = M::pow(sin_xi, k);
+        const double gamma_term = kappa_gamma_power<PREC>(d, gamma) * M::exp(-gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term;
         dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
@@ -160,6 +163,7 @@ RIM_DEV SymOrder sym_order(double n, LeungOrder *store)
 // J_n(z) and J'_n(z) as the reference's pkgw_bessel_j / pkgw_bessel_dj pair would
 // return them.  The two Leung evaluations (orders n and n+1) run through one
 // loop body so the expansions are inlined once.
+template <int PREC = 0>
 RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &djn)
 {
     const double n = so.n;
@@ -175,12 +179,12 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
         // Debye for both orders in one go (they share everything but x - n), Meissel order by order
         RIM_PROF_T(t_deb);
         double deb0 = 0., deb1 = 0.;
-        if ((c0 | c1) & LSEL_DEBYE) debye_eps_pair(so.o[0].n, so.o[1].n, z, &deb0, &deb1);
+        if ((c0 | c1) & LSEL_DEBYE) debye_eps_pair<PREC>(so.o[0].n, so.o[1].n, z, &deb0, &deb1);
         RIM_PROF_ADD(4, t_deb);
         RIM_PROF_T(t_mei);
         double mei0 = 0., mei1 = 0.;
-        if (c0 & LSEL_MEISSEL) mei0 = meissel_first(so.o[0], z);
-        if (c1 & LSEL_MEISSEL) mei1 = meissel_first(so.o[1], z);
+        if (c0 & LSEL_MEISSEL) mei0 = meissel_first<PREC>(so.o[0], z);
+        if (c1 & LSEL_MEISSEL) mei1 = meissel_first<PREC>(so.o[1], z);
         RIM_PROF_ADD(5, t_mei);
         if (!so.small) jv0 = leung_combine_code(c0, pos0, deb0, mei0);
         jv1 = leung_combine_code(c1, pos1, deb1, mei1);
@@ -212,7 +216,7 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
     djn = n * jn / z - jnp1;
 }
 
-template <int KIND>
+template <int KIND, int PREC = 0>
 RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const SymOrder &so, double gamma)
 {
     const double s = pt.s, n = so.n;
@@ -243,7 +247,7 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     double jn, djn;
     { RIM_PROF_T(t_cal); RIM_PROF_ADD(10, t_cal); }     // empty region: the timers' own cost
     RIM_PROF_T(t_bes);
-    sym_bessel_pair(so, z, jn, djn);
+    sym_bessel_pair<PREC>(so, z, jn, djn);
     RIM_PROF_ADD(2, t_bes);
     RIM_PROF_T(t_f);
     const double mj = m * jn;
@@ -257,11 +261,11 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     double f_term;
     if (pt.coeff == COEFF_EMISSION) {
         RIM_HIT(24);
-        f_term = calc_f<KIND>(d, gamma, cos_xi);
+        f_term = calc_f<KIND, PREC>(d, gamma, cos_xi);
     } else {
         double dfdg, dfdcx;
         RIM_HIT(25);
-        calc_f_derivatives<KIND>(d, gamma, cos_xi, dfdg, dfdcx);
+        calc_f_derivatives<KIND, PREC>(d, gamma, cos_xi, dfdg, dfdcx);
         const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
         f_term = dfdg + dfdcx_factor * dfdcx;
     }

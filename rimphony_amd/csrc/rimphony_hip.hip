@@ -293,7 +293,7 @@ __device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slo
 // A problem supplies the uniform context of a task, the parked task state and the five steps of
 // the resumable computation (begin / post / eval / consume / result).  Requests and results have
 // the same shape in both: (double abscissa, int tag) -> (double value, int status).
-template <int KIND>
+template <int KIND, int PREC = 0>
 struct SymphonyProblem {
     struct Ctx { SymPoint pt; DistParams d; };
     typedef TaskState Task;
@@ -311,7 +311,7 @@ struct SymphonyProblem {
     static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, Park *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
-    { sym_eval_pair<KIND>(c.pt, c.d, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
+    { sym_eval_pair<KIND, PREC>(c.pt, c.d, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
                                                    const SymBatch &B, double gval, int bst)
     { sym_consume(c.pt, g, outer, T, B, gval, bst); }
@@ -972,6 +972,7 @@ struct rimphony_ctx {
     // resident workgroups per CU of coop_kernel<P>, by problem (0 Symphony, 1 Heyvaerts) and distribution kind:
     // queried once per context (= per device) and instantiation
     int resident[2][4];
+    int resident_f32[4];            // ... and of the Symphony kernels' fp32-integrand variants
     // 0: this context has the GPU to itself (it holds the device's lock file); 1: another context or process had
     // the device first -- smaller persistent grids, no cooperative tail (see rimphony_ctx_create)
     int shared_mode;
@@ -1253,10 +1254,11 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     return RIMPHONY_OK;
 }
 
-template <int KIND>
+template <int KIND, int PREC = 0>
 static int launch_symphony(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
 {
-    const int rc = launch_coop<SymphonyProblem<KIND>>(c, a, st, c->ev_start, c->ev_stop, &c->resident[0][KIND]);
+    const int rc = launch_coop<SymphonyProblem<KIND, PREC>>(c, a, st, c->ev_start, c->ev_stop,
+                                                           PREC ? &c->resident_f32[KIND] : &c->resident[0][KIND]);
     if (rc == RIMPHONY_OK) c->ev_valid = 1;
     return rc;
 }
@@ -1282,7 +1284,7 @@ extern "C" int rimphony_batch_compute_device_ex(rimphony_ctx *c, int kind, size_
                                                 double *d_out, int32_t *d_status, uint64_t *d_work, void *stream)
 {
     if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;      // F32_INTEGRAND: not built
+    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
     if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
     std::lock_guard<std::mutex> lock(*c->mu);
@@ -1308,7 +1310,6 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
                                 const double *const *d_params, uint32_t coeff_mask, int precision,
                                 double *d_out, int32_t *d_status, uint64_t *d_work, hipStream_t st)
 {
-    (void) precision;
     ParamPtrs pp;
     int rc = make_param_ptrs(kind, d_params, pp);
     if (rc) return rc;
@@ -1375,11 +1376,21 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
         HIP_TRY(hipGetLastError());
     }
     if (a.nslots > 0) {
-        switch (kind) {
-        case 0: rc = launch_symphony<0>(c, a, st); break;
-        case 1: rc = launch_symphony<1>(c, a, st); break;
-        case 2: rc = launch_symphony<2>(c, a, st); break;
-        default: rc = launch_symphony<3>(c, a, st); break;
+        if (precision == RIMPHONY_PRECISION_F32_INTEGRAND) {
+            // the six Symphony coefficients with the fp32-core integrand (detmath.h); the Faraday pair below stays fp64
+            switch (kind) {
+            case 0: rc = launch_symphony<0, 1>(c, a, st); break;
+            case 1: rc = launch_symphony<1, 1>(c, a, st); break;
+            case 2: rc = launch_symphony<2, 1>(c, a, st); break;
+            default: rc = launch_symphony<3, 1>(c, a, st); break;
+            }
+        } else {
+            switch (kind) {
+            case 0: rc = launch_symphony<0>(c, a, st); break;
+            case 1: rc = launch_symphony<1>(c, a, st); break;
+            case 2: rc = launch_symphony<2>(c, a, st); break;
+            default: rc = launch_symphony<3>(c, a, st); break;
+            }
         }
         if (rc) return rc;
     }
@@ -1474,7 +1485,7 @@ extern "C" int rimphony_batch_compute_ex(rimphony_ctx *c, int kind, size_t n,
                                          uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work)
 {
     if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;
+    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];
@@ -1545,7 +1556,7 @@ extern "C" int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx
 {
     if (!ctxs || n_ctx < 1 || n_ctx > 64 || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
     for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64) return RIMPHONY_ENOTSUP;
+    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta || !out) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];

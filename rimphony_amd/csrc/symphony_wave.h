@@ -260,7 +260,7 @@ __device__ __forceinline__ bool sym_post(const SymPoint &pt, const GKLane &g, co
 // One or two requests: gamma_integral(n) for the given lobe (symphony.rs:312-389).  THE integrand site.
 // Two requests share their first rule application (wave_qag_pair); each half-wave also computes its own
 // request's order data and limits.
-template <int KIND>
+template <int KIND, int PREC = 0>
 __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistParams &dist, const GKLane &g,
                                               const IStore &inner, QagPark *qpark,
                                               double n0, int lobe0, double n1, int lobe1, bool have1,
@@ -292,7 +292,7 @@ __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistPara
         so.n = second ? n1 : n0;
         so.small = (fl & 1) != 0; so.np1_small = (fl & 2) != 0; so.dj_nan = (fl & 4) != 0;
         so.o = qpark->ord + (second ? 2 : 0);
-        return active ? gamma_integrand<KIND>(pt, dist, so, x) : 0.;
+        return active ? gamma_integrand<KIND, PREC>(pt, dist, so, x) : 0.;
     };
     int qs0, qs1;
     wave_qag_pair(f, g, inner, a0, b0, a1, b1, have1, false, 0., 1e-3, 5000, qpark, val0, qs0, val1, qs1);

@@ -173,3 +173,25 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_f32_integrand_variant_error_envelope(gpu_ctx):
+    """RIMPHONY_PRECISION_F32_INTEGRAND (BASELINE configs[4]): fp32-core exponentials / powers / cube root in the
+    Symphony integrand, kinematics and all sums in fp64.  No parity claim -- the error it carries, measured against the
+    fp64 path on the same rows (profiles/r2_f32_integrand_variant.txt has 16384-row runs): the bulk agrees to ~1e-8,
+    the tail is the noise-driven control flow amplifying 1e-7 differences.  An unknown precision is refused."""
+    from rimphony_amd import api
+    kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_8", 2048, start=1000000)
+    f64 = gpu_ctx.compute_batch(kind, s, th, params, 0x3F)
+    f32 = gpu_ctx.compute_batch(kind, s, th, params, 0x3F, precision=api.PRECISION_F32_INTEGRAND)
+    r = workload.compare_tables(f32, f64, 0x3F)
+    assert r["bit_identical"] < 0.5                         # it IS a different arithmetic
+    assert r["median"] < 1e-6 and r["within_1e-6"] > 0.95 and r["max"] < 5e-2, r
+    assert r["nan_only_here"] + r["nan_only_there"] <= 0.01 * r["coefficients"], r
+    # the Faraday pair is not part of the variant: fp64 bits
+    a = gpu_ctx.compute_batch(kind, s[:64], th[:64], [p[:64] for p in params], 0xC0)
+    b = gpu_ctx.compute_batch(kind, s[:64], th[:64], [p[:64] for p in params], 0xC0, precision=api.PRECISION_F32_INTEGRAND)
+    assert same_bits(a[:, 6:], b[:, 6:]).all()
+    with pytest.raises(capi.RimphonyError) as e:
+        gpu_ctx.compute_batch(kind, s[:4], th[:4], [p[:4] for p in params], 0x3F, precision=7)
+    assert "code -6" in str(e.value)

@@ -44,11 +44,17 @@ def test_series_bessel_functions_against_scipy(oracle):
     for nu in (1 / 3, -1 / 3, 2 / 3, -2 / 3):
         for g in (1e-6, 0.01, 0.3, 1., 3., 9.99):      # the I branch is used for g < 10
             assert abs(L.rimo_bessel_i(nu, g) / sp.iv(nu, g) - 1) < 2e-14
-    # the J/Y branch is only reachable for orders in (-1, 3) and small x (see rimo_heyvaerts.c)
-    for nu in (-0.9, -0.5, -0.2, 0.1, 0.5, 0.99, 1.3, 2.3, 2.7):
-        for x in (1e-5, 1e-3, 0.05, 0.25):
-            assert abs(L.rimo_bessel_jnu(nu, x) / sp.jv(nu, x) - 1) < 2e-14
-            assert abs(L.rimo_bessel_ynu(nu, x) / sp.yv(nu, x) - 1) < 1e-10   # reflection formula: cancellation near half-integers
+    # The J/Y branch (g >= 10) is only reachable where the quasi-resonant pomega range is limited by
+    # sqrt(sigma^2 - sigma0^2) rather than by the physical limit, i.e. sigma < 3, and there g >= 10 needs
+    # x = sqrt(sigma^2 - pomega^2 - sigma0^2) <= 0.23 (g = sqrt(8)/3 (sigma - x)^1.5 / sqrt(x); at sigma = 3.1 the
+    # physical limit already keeps x >= 0.456, g <= 6).  Orders sigma, sigma - 1 and their negatives: (-3, 3).
+    # Checked with margin: orders to +-3.6, x to 1.2.
+    for nu in (-0.9, -0.5, -0.2, 0.1, 0.5, 0.99, 1.3, 2.3, 2.7, 3.1, 3.6, -1.4, -2.3, -2.9, -3.6):
+        for x in (1e-5, 1e-3, 0.05, 0.25, 0.6, 1.2):
+            assert abs(L.rimo_bessel_jnu(nu, x) / sp.jv(nu, x) - 1) < 5e-14, (nu, x)
+            if nu > -1:
+                # reflection formula: cancellation near half-integers
+                assert abs(L.rimo_bessel_ynu(nu, x) / sp.yv(nu, x) - 1) < 1e-10, (nu, x)
     # exactly integer order: documented 2^-26 step off the pole of the reflection formula
     assert abs(L.rimo_bessel_ynu(2.0, 0.1) / sp.yv(2.0, 0.1) - 1) < 1e-6
     for z in (1 / 3, 2 / 3, 4 / 3, 5 / 3, -0.5, -1.5, 2.5, 7.25):
