@@ -43,8 +43,8 @@ FARADAY_FLOPS = {"cfg2_powerlaw_8": 498.0, "cfg3_thermal_8": 617.0}      # profi
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
 # HBM-side bytes per integrand sample of the symphony kernel, from rocprofv3 PMC (FETCH_SIZE and WRITE_SIZE, separate
 # passes, KB -> bytes; narrow accesses, so the gfx950 "wide read" doubling does not apply) on one 65536-row launch.
-PMC_PROFILE = "profiles/r1_final_pmc_symphony_65536pts.json"
-PMC_BYTES_PER_SAMPLE = (6.504e5 + 3.5443e7) * 1024. / 34183156539.
+PMC_PROFILE = "profiles/r2_pmc_symphony_65536pts.json"
+PMC_BYTES_PER_SAMPLE = (6.920e6 + 1.048e8) * 1024. / 34183156539.     # FETCH_SIZE + WRITE_SIZE (KB) / samples of that launch
 TABLE = 1_000_000
 EIGHT_ROWS, EIGHT_STEPS = 65536, 5
 THERMAL_ROWS, THERMAL_STEPS = 65536, 2

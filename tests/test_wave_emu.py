@@ -48,3 +48,9 @@ def test_symphony_coefficient_in_emulator(emu, oracle):
 
 def test_faraday_coefficient_in_emulator(emu, oracle):
     _run(emu, oracle, 1, [10.], 2, 1, 4e4, 0.4)
+
+
+def test_faraday_jy_branch_in_emulator(emu, oracle):
+    """Points whose quasi-resonant part reaches g >= 10 (sigma0 < 3): the J/Y branch of the elements."""
+    _run(emu, oracle, 1, [0.3], 2, 1, 1.5, 0.6)
+    _run(emu, oracle, 0, [2.5, 1., 1e12, 1e10], 2, 2, 2.0, 0.9)
