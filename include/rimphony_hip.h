@@ -107,7 +107,9 @@ typedef struct rimphony_ctx rimphony_ctx;
  * lifetime; a context created while that lock is held runs in SHARED mode (quarter-size grids, cooperative tail
  * off: slower, same results) or, with RIMPHONY_EXCLUSIVE=1 in the environment, is refused with RIMPHONY_EBUSY.
  * Calls on one context are serialised and ordered on the device whatever streams they name; different contexts
- * may be used from different threads freely. */
+ * may be used from different threads freely.
+ * RIMPHONY_OWNER_WAIT_US=<n> (test hook) shortens the 120 s an owner wave waits for its helpers before it recomputes
+ * a published batch itself; results do not depend on it. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);
 void rimphony_ctx_destroy(rimphony_ctx *ctx);
 int rimphony_ctx_shared_mode(const rimphony_ctx *ctx);   /* 0: owns the device, 1: shared mode */

@@ -978,6 +978,7 @@ struct rimphony_ctx {
     int shared_mode;
     int lock_fd;
     unsigned long long ticks_per_s;  // wall_clock64 rate of the device
+    unsigned long long owner_wait_ticks;   // how long an owner waits for its helpers before recomputing a batch itself
     // successive batch calls of a context share its workspace: each call's stream waits for the previous call's
     // work (ev_batch), and the calls themselves are serialised by mu
     hipEvent_t ev_batch;
@@ -1090,6 +1091,14 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
         c->ticks_per_s = (unsigned long long) khz * 1000ull;
+        c->owner_wait_ticks = 120ull * c->ticks_per_s;
+        // test hook: RIMPHONY_OWNER_WAIT_US=<microseconds> shortens the bound so that the recompute path runs
+        // (tests/test_gpu_boundary.py::test_owner_fallback_changes_no_bit)
+        const char *e = getenv("RIMPHONY_OWNER_WAIT_US");
+        if (e && e[0]) {
+            const unsigned long long us = strtoull(e, nullptr, 10);
+            c->owner_wait_ticks = us * c->ticks_per_s / 1000000ull;
+        }
     }
     if (hipMalloc(&c->d_queue, 16 * sizeof(unsigned long long)) != hipSuccess) { ctx_free(c); return RIMPHONY_ENOMEM; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
@@ -1243,7 +1252,7 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     b.board = c->no_assist ? nullptr : c->d_board;
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
     b.idle_ticks = 2ull * c->ticks_per_s;
-    b.owner_ticks = 120ull * c->ticks_per_s;
+    b.owner_ticks = c->owner_wait_ticks;
     // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);

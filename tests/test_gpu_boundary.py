@@ -195,3 +195,39 @@ def test_f32_integrand_variant_error_envelope(gpu_ctx):
     with pytest.raises(capi.RimphonyError) as e:
         gpu_ctx.compute_batch(kind, s[:4], th[:4], [p[:4] for p in params], 0x3F, precision=7)
     assert "code -6" in str(e.value)
+
+
+def test_owner_fallback_changes_no_bit(gpu_ctx):
+    """The cooperative tail's last resort: an owner whose helpers do not answer in time closes its batch, evaluates all
+    of it itself and never publishes again.  With the bound cut to 1 microsecond (RIMPHONY_OWNER_WAIT_US) nearly every
+    published batch takes that path, helpers still write late results into abandoned slots -- and the table is the
+    same, bit for bit and status for status, as the normal run's (run in a child process: the variable is read when
+    a context is created, and the child's context runs in shared mode next to this one unless it comes first)."""
+    code = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+from rimphony_amd import api, workload
+ctx = api.Context(0)
+kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_8", 192, start=1000000)
+out, st = ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+np.save(sys.argv[1], out); np.save(sys.argv[2], st)
+print("shared" if ctx.shared_mode() else "exclusive")
+''' % ROOT
+    import tempfile
+    gpu_ctx.close()                 # release the device lock: the children must own the GPU to use the cooperative tail
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            res = {}
+            for name, env_extra in (("normal", {}), ("impatient", {"RIMPHONY_OWNER_WAIT_US": "1"})):
+                env = dict(os.environ, **env_extra)
+                o, s_ = os.path.join(d, name + "_o.npy"), os.path.join(d, name + "_s.npy")
+                r = subprocess.run([sys.executable, "-c", code, o, s_], capture_output=True, text=True, env=env, timeout=600)
+                assert r.returncode == 0, r.stderr[-2000:]
+                assert "exclusive" in r.stdout
+                res[name] = (np.load(o), np.load(s_))
+            assert same_bits(res["normal"][0], res["impatient"][0]).all()
+            assert (res["normal"][1] == res["impatient"][1]).all()
+    finally:
+        # give the session fixture a live context back
+        gpu_ctx.__init__(0)
