@@ -280,6 +280,18 @@ int rimphony_calc_f_batch_device(rimphony_ctx *ctx, int dist_kind, const double 
 int rimphony_calc_f_batch(rimphony_ctx *ctx, int dist_kind, const double *params, double norm_override, size_t count,
                           const double *gamma, const double *cos_xi, double *f, double *dfdg, double *dfdcx);
 
+/* Unit seams of the Heyvaerts (Faraday) path for ONE parameter point (host `params`), stokes = RIMPHONY_STOKES_Q (the
+ * "h" elements, rho_Q) or _V (the "f" elements, rho_V):
+ *   element: the inner integrand -- qr != 0: h_qr / f_qr_element at sigma = d_fixed[i], pomega = d_v[i]
+ *            (heyvaerts.rs:302-373, 400-447); qr == 0: h_nr / f_nr_element at pomega = d_fixed[i], sigma = d_v[i]
+ *            (heyvaerts.rs:379-394, 453-468);
+ *   outer:   the outer integrand = one inner integral -- qr_outer_integrand(sigma = d_u[i]) / nr_outer_integrand(pomega =
+ *            d_u[i]) (heyvaerts.rs:213-250, 262-296); NaN where the inner QAG fails. */
+int rimphony_hey_element_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params, int stokes, double s, double theta,
+                                      int qr, size_t count, const double *d_fixed, const double *d_v, double *d_out, void *stream);
+int rimphony_hey_outer_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params, int stokes, double s, double theta,
+                                    int qr, size_t count, const double *d_u, double *d_out, void *stream);
+
 /* Self-test seam for the wavefront QAG (gsl.rs:156-207 semantics) on built-in
  * integrands made of + - * / sqrt only, so CPU and GPU agree bit for bit:
  *   family 0: 1 / (1 + ((x - p0) * p1)^2)         family 1: sqrt(|x - p0|) * p1

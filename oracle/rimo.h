@@ -129,6 +129,9 @@ void rimo_compute_all_dimensionless(const rimo_dist *d, double s, double theta, 
 double rimo_compute_cgs(const rimo_dist *d, int coeff, int stokes, double nu, double b, double n_e, double theta);
 
 double rimo_hey_element(const rimo_dist *d, int stokes, double s, double theta, int qr, double fixed, double v);
+/* diagnostic: one OUTER-integrand sample = one inner integral (heyvaerts.rs:213-250 nr_outer_integrand at pomega = u,
+ * 262-296 qr_outer_integrand at sigma = u); NaN where the inner QAG fails, as `.unwrap_or(NAN)` does upstream */
+double rimo_hey_outer_integrand(const rimo_dist *d, int stokes, double s, double theta, int qr, double u);
 
 /* diagnostics (lib.rs:254-298) */
 double rimo_gamma_integrand(const rimo_dist *d, int coeff, int stokes, double s, double theta, double n, double gamma);

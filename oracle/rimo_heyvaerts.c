@@ -403,6 +403,26 @@ done:
     return result;
 }
 
+/* diagnostic: one outer-integrand sample (an inner integral) */
+double rimo_hey_outer_integrand(const rimo_dist *d, int stokes, double s, double theta, int qr, double u)
+{
+    hey_state st;
+    st.d = d;
+    st.stokes = stokes;
+    st.s = s;
+    m_sincos(theta, &st.sin_observer_angle, &st.cos_observer_angle);
+    st.sigma0 = s * st.sin_observer_angle;
+    st.sigma0_sq = st.sigma0 * st.sigma0;
+    st.sigma = st.pomega = st.x = st.gamma = st.mu = RIM_NAN;
+    st.fixed = RIM_NAN;
+    st.ows = NULL;
+    st.iws = rimo_workspace_alloc(4096);
+    st.c = NULL;
+    const double v = qr ? qr_outer_integrand(u, &st) : nr_outer_integrand(u, &st);
+    rimo_workspace_free(st.iws);
+    return v;
+}
+
 /* diagnostic: one inner-integrand sample (qr: quasi-resonant element at fixed sigma, variable
  * pomega; else non-resonant element at fixed pomega, variable sigma) */
 double rimo_hey_element(const rimo_dist *d, int stokes, double s, double theta, int qr, double fixed, double v)

@@ -316,6 +316,28 @@ class Context:
         torch.cuda.synchronize(self._dev())
         return f.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()
 
+    def hey_element_batch(self, kind, params, stokes, s, theta, qr, fixed, v):
+        """Heyvaerts inner integrand (h/f element, quasi-resonant if qr) of one parameter point over arrays."""
+        df, dv = self._as_dev(fixed), self._as_dev(v)
+        out = torch.empty_like(df)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_hey_element_batch_device(
+            self.handle, kind, par, int(stokes), s, theta, int(qr), df.numel(), ctypes.c_void_p(df.data_ptr()),
+            ctypes.c_void_p(dv.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()), "rimphony_hey_element_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
+    def hey_outer_batch(self, kind, params, stokes, s, theta, qr, u):
+        """Heyvaerts outer integrand (one inner integral per abscissa) of one parameter point over an array."""
+        du = self._as_dev(u)
+        out = torch.empty_like(du)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_hey_outer_batch_device(
+            self.handle, kind, par, int(stokes), s, theta, int(qr), du.numel(), ctypes.c_void_p(du.data_ptr()),
+            ctypes.c_void_p(out.data_ptr()), self._stream()), "rimphony_hey_outer_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def qag_selftest(self, family, p0, p1, a, b, epsabs, epsrel, limit):
         fam = torch.as_tensor(family, dtype=torch.int32).to(self._dev()).contiguous()
         d = [self._as_dev(v) for v in (p0, p1, a, b)]

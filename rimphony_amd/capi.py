@@ -17,6 +17,7 @@ SYMBOLS = [
     "rimphony_gamma_integral_batch_device", "rimphony_n_integral_batch_device", "rimphony_gamma_contribution_batch_device", "rimphony_calc_f_batch_device", "rimphony_calc_f_batch", "rimphony_qag_selftest_device", "rimphony_highfreq_batch_device", "rimphony_highfreq_batch", "rimphony_detmath_batch_device", "pkgw_bessel_j", "pkgw_bessel_dj",
     "rimphony_ctx_shared_mode", "rimphony_last_error", "rimphony_batch_compute_device_ex", "rimphony_batch_compute_ex",
     "rimphony_batch_compute_multi", "rimphony_status_histogram_device",
+    "rimphony_hey_element_batch_device", "rimphony_hey_outer_batch_device",
 ]
 
 
@@ -115,6 +116,12 @@ def load():
     lib.rimphony_batch_compute_multi.restype = c_int
     lib.rimphony_batch_compute_multi.argtypes = [POINTER(c_void_p), c_int, c_int, c_size_t, dp, dp, POINTER(dp), c_uint32,
                                                  c_int, dp, POINTER(c_int32), POINTER(c_uint64)]
+    lib.rimphony_hey_element_batch_device.restype = c_int
+    lib.rimphony_hey_element_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_double, c_double, c_int, c_size_t,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.rimphony_hey_outer_batch_device.restype = c_int
+    lib.rimphony_hey_outer_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_double, c_double, c_int, c_size_t,
+                                                    c_void_p, c_void_p, c_void_p]
     lib.rimphony_status_histogram_device.restype = c_int
     lib.rimphony_status_histogram_device.argtypes = [c_void_p, c_size_t, c_void_p, POINTER(c_uint64), c_void_p]
     _lib = lib

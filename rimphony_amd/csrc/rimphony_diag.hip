@@ -3,6 +3,7 @@
 // (calc_f / calc_f_derivatives over arrays).  See rimphony_internal.h for why
 // they are not in rimphony_hip.hip.
 #include "rimphony_internal.h"
+#include "heyvaerts_wave.h"
 
 using namespace rim;
 
@@ -252,4 +253,113 @@ extern "C" int rimphony_calc_f_batch(rimphony_ctx *c, int kind, const double *pa
     } while (0);
     (void) hipFree(buf);
     return rc;
+}
+
+
+// ---- Heyvaerts unit seams (heyvaerts.rs:213-296 outer integrands, 302-468 elements) ---------------------------
+// The Faraday coefficients are compared with the oracle end to end; these two seams let a divergence be localised:
+// the element functions (one thread per (fixed, v) pair) and the outer integrands (one wave per abscissa: the inner
+// QAG of hey_eval_request).
+static __device__ HeyPoint hey_point_of(const PointArgs &pa)
+{
+    HeyPoint pt;
+    pt.s = pa.s;
+    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
+    pt.sigma0 = pt.s * pt.sin_th;
+    pt.sigma0_sq = pt.sigma0 * pt.sigma0;
+    pt.stokes = pa.stokes;
+    return pt;
+}
+
+template <int KIND>
+__global__ void hey_element_kernel(PointArgs pa, const double *norm_ptr, const double *series_tab, int qr, size_t count,
+                                   const double *fixed, const double *v, double *out)
+{
+    __shared__ double s_ser[4 * RIM_SERIES_LDS_ROW];
+    for (int k = threadIdx.x; k < 4 * RIM_SERIES_LDS_ROW; k += blockDim.x)
+        s_ser[k] = series_tab[(k / RIM_SERIES_LDS_ROW) * RIM_SERIES_ROW + k % RIM_SERIES_LDS_ROW];
+    __syncthreads();
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const HeyPoint pt = hey_point_of(pa);
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    const HeyConsts hc = hey_consts(series_tab, s_ser);
+    out[i] = hey_element<KIND>(pt, d, hc, qr != 0, fixed[i], v[i]);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const double *norm_ptr, const double *series_tab, int qr,
+                                                       size_t count, const double *u, double *out, double *spill_base)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    __shared__ double s_ser[4 * RIM_SERIES_LDS_ROW];
+    __shared__ QagParkBase s_qpark;
+    const GKLane g = gk_lane_init(s_tab);
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
+    for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64)
+        s_ser[i] = series_tab[(i / RIM_SERIES_LDS_ROW) * RIM_SERIES_ROW + i % RIM_SERIES_LDS_ROW];
+    __syncthreads();
+    HeyPoint pt = hey_point_of(pa);
+    pt.s = uni(pt.s); pt.sin_th = uni(pt.sin_th); pt.cos_th = uni(pt.cos_th);
+    pt.sigma0 = uni(pt.sigma0); pt.sigma0_sq = uni(pt.sigma0_sq);
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    const HeyConsts hc = hey_consts(series_tab, s_ser);
+    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
+        int st = 0;
+        const double val = hey_eval_request<KIND>(pt, d, hc, g, inner, &s_qpark, uni(u[i]), qr, st);
+        if (g.lane == 0) out[i] = val;
+    }
+}
+
+const double *rim_ctx_series(const rimphony_ctx *c);
+
+extern "C" int rimphony_hey_element_batch_device(rimphony_ctx *c, int kind, const double *params, int stokes, double s, double theta,
+                                                 int qr, size_t count, const double *d_fixed, const double *d_v, double *d_out,
+                                                 void *stream)
+{
+    if (!c || (count && (!d_fixed || !d_v || !d_out)) || (stokes != RIMPHONY_STOKES_Q && stokes != RIMPHONY_STOKES_V)) return RIMPHONY_EINVAL;
+    hipStream_t st = (hipStream_t) stream;
+    PointArgs pa;
+    int rc = rim_point_setup(c, kind, params, 0, stokes, 0, s, theta, st, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    const double *norm = rim_ctx_norm(c);
+    const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(hey_element_kernel<0>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
+    case 1: hipLaunchKernelGGL(hey_element_kernel<1>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
+    case 2: hipLaunchKernelGGL(hey_element_kernel<2>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
+    default: hipLaunchKernelGGL(hey_element_kernel<3>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_hey_outer_batch_device(rimphony_ctx *c, int kind, const double *params, int stokes, double s, double theta,
+                                               int qr, size_t count, const double *d_u, double *d_out, void *stream)
+{
+    if (!c || (count && (!d_u || !d_out)) || (stokes != RIMPHONY_STOKES_Q && stokes != RIMPHONY_STOKES_V)) return RIMPHONY_EINVAL;
+    hipStream_t st = (hipStream_t) stream;
+    PointArgs pa;
+    int rc = rim_point_setup(c, kind, params, 0, stokes, 0, s, theta, st, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    unsigned grid = 0;
+    rc = rim_wave_grid(c, count, 16, &grid);
+    if (rc) return rc;
+    const double *norm = rim_ctx_norm(c);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(hey_outer_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    case 1: hipLaunchKernelGGL(hey_outer_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    case 2: hipLaunchKernelGGL(hey_outer_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    default: hipLaunchKernelGGL(hey_outer_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
 }

@@ -1815,6 +1815,7 @@ int rim_wave_grid(rimphony_ctx *c, size_t count, int waves_per_cu, unsigned *gri
     return ensure_spill(c, *grid);
 }
 const double *rim_ctx_norm(const rimphony_ctx *c) { return c->d_norm; }
+const double *rim_ctx_series(const rimphony_ctx *c) { return c->d_series; }
 double *rim_ctx_spill(const rimphony_ctx *c) { return c->d_spill; }
 
 extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, const double *params,

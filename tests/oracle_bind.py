@@ -70,6 +70,10 @@ def load(flavour="det"):
     L.rimo_gamma_contribution.argtypes = [POINTER(Dist), c_int, c_int, c_double, c_double, c_double]
     L.rimo_n_integral.restype = c_int
     L.rimo_n_integral.argtypes = [POINTER(Dist), c_int, c_int, c_int, c_double, c_double, c_double, c_double, dp]
+    L.rimo_hey_element.restype = c_double
+    L.rimo_hey_element.argtypes = [POINTER(Dist), c_int, c_double, c_double, c_int, c_double, c_double]
+    L.rimo_hey_outer_integrand.restype = c_double
+    L.rimo_hey_outer_integrand.argtypes = [POINTER(Dist), c_int, c_double, c_double, c_int, c_double]
     L.rimo_highfreq.restype = c_int; L.rimo_highfreq.argtypes = [c_int, dp, c_double, c_double, dp]
     L.rimo_bessel_k012.restype = None; L.rimo_bessel_k012.argtypes = [c_double, dp]
     L.rimo_build_flavour.restype = ctypes.c_char_p

@@ -570,6 +570,73 @@ def test_gamma_contribution_diagnostic_bit_exact(gpu_ctx, oracle):
             assert np.isfinite(ref).sum() >= 6
 
 
+HEY_SEAM_POINTS = [   # (kind, params, s, theta): sigma0 = s sin(theta) spans the J/Y branch (< 3) and the large-order branches
+    (1, [10.], 4e4, 0.4), (1, [0.3], 1.5, 0.6), (0, [2.5, 1., 1e12, 1e10], 2.0, 0.9), (0, [3.1, 1., 1e12, 1e10], 60., 1.1),
+    (2, [2.8, 1.2, 1., 1e12, 1e10], 25., 0.7), (3, [3.3, 6.0, 0.8, 1e10], 9., 0.5),
+]
+
+
+def _hey_qr_start(sigma0):
+    """Where the quasi-resonant region begins: both pomega_max expressions of heyvaerts.rs:262-296 are real."""
+    return max(sigma0, 3 ** -0.5 * sigma0 ** 1.5)
+
+
+def _hey_seam_inputs(rng, s, th, qr, n):
+    """(fixed, v) inside the integration domains of heyvaerts.rs:213-296: non-resonant -- fixed = pomega, v = sigma in
+    [sigma_min, sigma_max]; quasi-resonant -- fixed = sigma >= sigma0, v = pomega in [-pomega_max, pomega_max]."""
+    sigma0 = s * math.sin(th)
+    if not qr:
+        pomega = rng.uniform(-1., 1., n) * np.exp(rng.uniform(math.log(3.), math.log(3e3), n)) * max(sigma0, 1.)
+        smin = np.sqrt(pomega ** 2 + sigma0 ** 2)
+        smax = np.maximum(3 ** -0.5 * smin ** 1.5, smin)
+        return pomega, smin + (smax - smin) * rng.random(n)
+    sigma = _hey_qr_start(sigma0) * (1. + np.exp(rng.uniform(math.log(1e-3), math.log(3e2), n)))
+    with np.errstate(invalid="ignore"):
+        pmax = np.fmin(np.sqrt(3 ** (2. / 3.) * sigma ** (4. / 3.) - sigma0 ** 2), np.sqrt(sigma ** 2 - sigma0 ** 2))
+    pmax = np.nan_to_num(pmax, nan=0.)
+    return sigma, pmax * rng.uniform(-1., 1., n)
+
+
+@pytest.mark.parametrize("case", range(len(HEY_SEAM_POINTS)))
+def test_heyvaerts_elements_bit_exact(gpu_ctx, oracle, case):
+    """h_qr / h_nr / f_qr / f_nr_element (heyvaerts.rs:302-468), the inner integrands of the Faraday double integral,
+    sample by sample against the oracle's restatement."""
+    kind, par, s, th = HEY_SEAM_POINTS[case]
+    rng = np.random.default_rng(700 + case)
+    d, st = oracle_bind.mkdist(oracle, kind, par)
+    assert st == 0
+    for stokes in (1, 2):
+        for qr in (0, 1):
+            fixed, v = _hey_seam_inputs(rng, s, th, qr, 1536)
+            got = gpu_ctx.hey_element_batch(kind, par, stokes, s, th, qr, fixed, v)
+            ref = np.array([oracle.rimo_hey_element(ctypes.byref(d), stokes, s, th, qr, float(a), float(b)) for a, b in zip(fixed, v)])
+            report_mismatch("hey_element case %d stokes %d qr %d" % (case, stokes, qr), got, ref, lambda i: (fixed[i], v[i]))
+            assert np.isfinite(ref).sum() > 1000
+
+
+@pytest.mark.parametrize("case", range(len(HEY_SEAM_POINTS)))
+def test_heyvaerts_outer_integrands_bit_exact(gpu_ctx, oracle, case):
+    """nr_outer_integrand / qr_outer_integrand (heyvaerts.rs:213-250, 262-296): one inner QAG per abscissa, the wave-level
+    quadrature of the Faraday kernel, against the oracle (NaN where the inner integral fails; exactly 0 where the sigma
+    range is empty)."""
+    kind, par, s, th = HEY_SEAM_POINTS[case]
+    rng = np.random.default_rng(800 + case)
+    d, st = oracle_bind.mkdist(oracle, kind, par)
+    assert st == 0
+    sigma0 = s * math.sin(th)
+    n = 40
+    for stokes in (1, 2):
+        for qr in (0, 1):
+            if qr:
+                u = _hey_qr_start(sigma0) * (1. + np.exp(rng.uniform(math.log(1e-3), math.log(1e2), n)))
+            else:
+                u = rng.uniform(-1., 1., n) * np.exp(rng.uniform(math.log(0.3), math.log(1e3), n)) * max(sigma0, 1.)
+            got = gpu_ctx.hey_outer_batch(kind, par, stokes, s, th, qr, u)
+            ref = np.array([oracle.rimo_hey_outer_integrand(ctypes.byref(d), stokes, s, th, qr, float(x)) for x in u])
+            report_mismatch("hey_outer case %d stokes %d qr %d" % (case, stokes, qr), got, ref, lambda i: u[i])
+            assert np.isfinite(ref).sum() > n // 2
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_distribution_function_seam_bit_exact(gpu_ctx, oracle, kind):
     """DistributionFunction::calc_f / calc_f_derivatives (lib.rs:111-146) through the C ABI against the oracle's
