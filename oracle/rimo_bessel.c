@@ -150,7 +150,7 @@ static double debye_eps_exp(const double n, const double x)
         return RIM_NAN;
 
     const double ez = x - n;
-    const double z = m_pow(x, 1. / 3.);
+    const double z = m_cbrt(x);     /* bessel.c:180: pow(x, 1./3.) */
     const double t3 = z * z;
     const double t4 = x * z;
     const double t10 = t4 * t4;

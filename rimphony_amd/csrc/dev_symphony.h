@@ -54,14 +54,14 @@ RIM_DEV void dist_prepare(DistParams &d, double norm)
     }
 }
 
-// (1 + (gamma - 1) / (kappa width))^-(kappa + 1) of the pitchy-kappa distribution
+// (1 + (gamma - 1) / (kappa width))^-(kappa + 1) exp(-gamma / gamma_cutoff) of the pitchy-kappa distribution
 template <int PREC = 0>
-RIM_DEV double kappa_gamma_power(const DistParams &d, double gamma)
+RIM_DEV double kappa_gamma_term(const DistParams &d, double gamma)
 {
     const double base = 1. + (gamma - 1.) * d.inv_kappa_width;
     const double y = -(d.par[0] + 1.);
-    if (rim_bits(d.par[4]) != 0) return RimMath<PREC>::pow_normal(base, y);     // wave-uniform test
-    return rim_pow(base, y);
+    if (rim_bits(d.par[4]) != 0) return RimMath<PREC>::powexp_normal(base, y, -gamma * d.inv_gamma_cutoff);     // wave-uniform test
+    return rim_pow(base, y) * RimMath<PREC>::exp(-gamma * d.inv_gamma_cutoff);
 }
 
 template <int KIND, int PREC = 0>
@@ -72,7 +72,7 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
         if (gamma < d.par[1] || gamma > d.par[2]) return 0.;
         RIM_HIT(19);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        return d.norm * M::pow_normal(gamma, -d.par[0]) * M::exp(-gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
+        return d.norm * M::powexp_normal(gamma, -d.par[0], -gamma * d.inv_gamma_cutoff) / (gamma * gamma * beta);
     } else if (KIND == DIST_THERMAL_JUETTNER) {
         return d.norm * M::exp(d.neg_inverse_t * gamma);
     } else if (KIND == DIST_PITCHY_PL) {
@@ -80,12 +80,12 @@ RIM_DEV double calc_f(const DistParams &d, double gamma, double cos_xi)
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = M::pow(sin_xi, d.par[1]);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = M::pow_normal(gamma, -d.par[0]) * M::exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = M::powexp_normal(gamma, -d.par[0], -gamma * d.inv_gamma_cutoff);
         return d.norm * pa_term * gamma_term / (gamma * gamma * beta);
     } else {
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = M::pow(sin_xi, d.par[2]);
-        const double gamma_term = kappa_gamma_power<PREC>(d, gamma) * M::exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = kappa_gamma_term<PREC>(d, gamma);
         return d.norm * pa_term * gamma_term;
     }
 }
@@ -99,8 +99,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         RIM_HIT(20);
         const double p_plus_1 = d.par[0] + 1.;
         const double g2_minus_1 = gamma * gamma - 1.;
-        dfdg = -d.norm * M::pow_normal(gamma, -p_plus_1) / rim_sqrt(g2_minus_1) *
-            M::exp(-gamma * d.inv_gamma_cutoff) *
+        dfdg = -d.norm * M::powexp_normal(gamma, -p_plus_1, -gamma * d.inv_gamma_cutoff) / rim_sqrt(g2_minus_1) *
             (p_plus_1 / gamma + gamma / g2_minus_1 + d.inv_gamma_cutoff);
         dfdcx = 0.;
     } else if (KIND == DIST_THERMAL_JUETTNER) {
@@ -112,7 +111,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = M::pow(sin_xi, k);
         const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
-        const double gamma_term = M::pow_normal(gamma, -p) * M::exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = M::powexp_normal(gamma, -p, -gamma * d.inv_gamma_cutoff);
         const double f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
         dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
@@ -120,7 +119,7 @@ RIM_DEV void calc_f_derivatives(const DistParams &d, double gamma, double cos_xi
         const double kappa = d.par[0], width = d.par[1], k = d.par[2];
         const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
         const double pa_term = M::pow(sin_xi, k);
-        const double gamma_term = kappa_gamma_power<PREC>(d, gamma) * M::exp(-gamma * d.inv_gamma_cutoff);
+        const double gamma_term = kappa_gamma_term<PREC>(d, gamma);
         const double f = d.norm * pa_term * gamma_term;
         dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);
         dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
@@ -183,8 +182,8 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
         RIM_PROF_ADD(4, t_deb);
         RIM_PROF_T(t_mei);
         double mei0 = 0., mei1 = 0.;
-        if (c0 & LSEL_MEISSEL) mei0 = meissel_first<PREC>(so.o[0], z);
-        if (c1 & LSEL_MEISSEL) mei1 = meissel_first<PREC>(so.o[1], z);
+        if (c0 & LSEL_MEISSEL) mei0 = meissel_first<PREC, true>(so.o[0], z);
+        if (c1 & LSEL_MEISSEL) mei1 = meissel_first<PREC, true>(so.o[1], z);
         RIM_PROF_ADD(5, t_mei);
         if (!so.small) jv0 = leung_combine_code(c0, pos0, deb0, mei0);
         jv1 = leung_combine_code(c1, pos1, deb1, mei1);
@@ -266,8 +265,16 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
         double dfdg, dfdcx;
         RIM_HIT(25);
         calc_f_derivatives<KIND, PREC>(d, gamma, cos_xi, dfdg, dfdcx);
-        const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
-        f_term = dfdg + dfdcx_factor * dfdcx;
+        if (KIND == DIST_POWER_LAW || KIND == DIST_THERMAL_JUETTNER) {
+            // dfdcx is the constant +0 (isotropic distributions): dfdcx_factor * dfdcx is a zero with the sign of the
+            // factor (a NaN only where the sample is a NaN through cos_xi anyway), and for gamma > 0 the factor
+            // (beta cos_th - cos_xi) / (gamma - 1 / gamma) has the sign of (beta cos_th - cos_xi) (gamma - 1): the
+            // same bits -- signed zeros of f_term included -- without the two divisions.
+            f_term = dfdg + ((beta * cos_th - cos_xi) * dfdcx) * (gamma - 1.);
+        } else {
+            const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
+            f_term = dfdg + dfdcx_factor * dfdcx;
+        }
     }
 
     RIM_PROF_ADD(6, t_f);

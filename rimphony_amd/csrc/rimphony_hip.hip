@@ -1862,6 +1862,7 @@ __global__ void detmath_kernel(int op, size_t n, const double *x, const double *
     case 7: rim_sincos(a, &r, &t); break;
     case 8: rim_sincos(a, &t, &r); break;
     case 9: r = rim_div_by(a, b, 1. / b); break;
+    case 10: r = rim_cbrt_normal(a); break;
     default: r = RIM_NAN; break;
     }
     out[i] = r;
@@ -1870,7 +1871,7 @@ __global__ void detmath_kernel(int op, size_t n, const double *x, const double *
 extern "C" int rimphony_detmath_batch_device(rimphony_ctx *c, int op, size_t n, const double *d_x, const double *d_y,
                                              double *d_out, void *stream)
 {
-    if (!c || op < 0 || op > 9) return RIMPHONY_EINVAL;
+    if (!c || op < 0 || op > 10) return RIMPHONY_EINVAL;
     if (n == 0) return RIMPHONY_OK;
     if (!d_x || !d_out || ((op == 3 || op == 9) && !d_y)) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));

@@ -29,6 +29,7 @@ double t_sqrt(double x){return rim_sqrt(x);}
 double t_pow_pos(double x,double y){return rim_pow_pos(x,y);}
 double t_pow_normal(double x,double y){return rim_pow_normal(x,y);}
 double t_div_by(double a,double b){return rim_div_by(a,b,1.0/b);}
+double t_cbrt(double x){return rim_cbrt_normal(x);}
 '''
 
 
@@ -127,6 +128,21 @@ def test_pow15(dm):
         assert abs((mp.mpf(got) - ref) / ref) < 3e-16
 
 
+def test_cbrt(dm):
+    """The cube root of the Debye expansion (bessel.c:180 calls pow(x, 1./3.)): below 1 ulp over the whole normal
+    range, exact on perfect cubes; the exponent 0.333...31 of the reference's call is itself 1.85e-17 ln x away."""
+    dm.t_cbrt.restype = ctypes.c_double
+    dm.t_cbrt.argtypes = [ctypes.c_double]
+    mp.mp.prec = 200
+    rng = np.random.default_rng(9)
+    xs = np.concatenate([np.exp(rng.uniform(-700., 700., 3000)), 30. * np.exp(rng.uniform(0., 34.5, 3000)),
+                         [2.2250738585072014e-308, 1.7976931348623157e308, 1., 8., 27.]])
+    w = worst(dm.t_cbrt, lambda x: mp.cbrt(x), xs)
+    assert w < 1.0, w
+    for k in (2., 3., 5., 10., 1e5, 31., 12345.):
+        assert dm.t_cbrt(k * k * k) == k
+
+
 def test_log10_region(dm):
     """The plain-double log10 of the Bessel region variable: a few ulp (<= 4) on (0, 1], its whole domain."""
     dm.t_log10_region.restype = ctypes.c_double
@@ -193,6 +209,8 @@ def test_leaf_functions_same_bits_on_gpu(dm):
     assert same(ctx.detmath_batch("sin", xa), cpu("t_sin", xa)) and same(ctx.detmath_batch("cos", xa), cpu("t_cos", xa))
     a, b = np.exp(rng.uniform(-50., 50., 20000)), 30. + np.floor(rng.random(20000) * 1e6)
     assert same(ctx.detmath_batch("div_by", a, b), a / b)
+    xc = np.concatenate([np.exp(rng.uniform(-708., 709., 20000)), 30. * np.exp(rng.uniform(0., 34.5, 20000))])
+    assert same(ctx.detmath_batch("cbrt", xc), cpu("t_cbrt", xc))
     ctx.close()
 
 
