@@ -82,6 +82,17 @@ __device__ __forceinline__ double rim_fma_k(double a, double b, double k)
 #else
 #define rim_fma_k(a, b, k) rim_fma(a, b, k)
 #endif
+/* fma(a, K, 1) for a compile-time constant K: K in an SGPR pair, the 1 an inline constant (1 VALU issue) */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rim_fma_k1(double a, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+}
+#else
+#define rim_fma_k1(a, k) rim_fma(a, k, 1.0)
+#endif
 /* a / b given binv = RN(1 / b): the correctly rounded quotient in 3 operations instead of the
  * ~11-instruction IEEE division sequence (Markstein: q = RN(a binv), r = a - q b exactly by FMA,
  * RN(q + r binv) = RN(a / b)).  For finite a, normal b and a quotient in the normal range -- the
@@ -459,6 +470,40 @@ RIM_FN double rim_pow_normal(double x, double y)
     if (ph > 709.782712893384) return RIM_INF;
     if (ph < -745.2) return 0.0;
     return rim_exp_dd_core(ph, pl);
+}
+
+/* y^(-1/4) for a positive normal finite y, ~1 ulp (tests/test_detmath.py), from integer and correctly rounded fp64
+ * operations only (bit-identical on the CPU and the GPU): the exponent trick (3.1 %), two third-order steps
+ * w <- w (1 + a + 5/2 a^2) with a = (1 - y w^4) / 4, and a first-order one.  The Meissel expansion needs
+ * Z = sqrt(y), 1 / Z^3 and 1 / sqrt(Z) of one y (bessel.c:100-122): all three are products of powers of w, where the
+ * literal evaluation takes two square roots and two divisions. */
+RIM_FN double rim_rqrt4_normal(double y)
+{
+    const uint32_t hi = (uint32_t) (rim_bits(y) >> 32);
+    double w = rim_frombits((uint64_t) (0x4feb0c00u - (hi >> 2)) << 32);
+    const double y4 = 0.25 * y;
+    for (int it = 0; it < 2; it++) {
+        const double w2 = w * w;
+        const double a = rim_fma_k(-y4, w2 * w2, 0.25);
+        w = rim_fma(w * a, rim_fma_k1(a, 2.5), w);
+    }
+    const double w2 = w * w;
+    const double a = rim_fma_k(-y4, w2 * w2, 0.25);
+    return rim_fma(w, a, w);
+}
+
+/* The three roots of the Meissel expansion from one y = eps (1 + z) in [2^-53, 2) (bessel.c:100-122: Z = sqrt(y),
+ * U = 1 / (n Z^3), factor = 1 / ((n + 1) sqrt(Z))): w = y^(-1/4) gives 1 / sqrt(Z) = w, 1 / Z^3 = w^6 and
+ * Z = y w^2, the latter polished by one Newton step to within an ulp because the exponent n (log(x / (1 + Z)) - (1 - Z))
+ * multiplies its error by n Z^2.  22 fp64 operations where two square roots and two divisions take 42. */
+RIM_FN void rim_meissel_roots(double y, double *Z, double *inv_z3, double *inv_sqrt_z)
+{
+    const double w = rim_rqrt4_normal(y);
+    const double w2 = w * w;
+    const double z0 = y * w2;
+    *Z = rim_fma(rim_fma(-z0, z0, y) * w2, 0.5, z0);
+    *inv_z3 = (w2 * w2) * w2;
+    *inv_sqrt_z = w;
 }
 
 /* x^y exp(e) for a positive normal finite x as ONE exponential, exp(y ln x + e) with the sum carried in double-double:

@@ -105,7 +105,7 @@ struct LeungOrder {
     // relative guard band of 1e-3 pushed outwards: a ratio outside [r_*_dn, r_*_up] is on the same
     // side of the threshold as its log10 (which is what bessel.c compares) and needs no logarithm.
     double r_lo_dn, r_hi_up, rp_dn, rp_up;
-    double ninv, np1;
+    double ninv, np1inv;        // 1 / n, 1 / (n + 1)
     double vsum2;               // -(ninv (420 + (-14 + (-4 + 3 t2) t2) t2)) / 5040
     double lgam;                // lgamma(n)
     double small_eps_const;     // 0.5 log(0.5 n / pi) + loggamma_exp
@@ -125,7 +125,7 @@ RIM_DEV LeungOrder leung_order(double n)
     o.rp_dn = guard_pow10(o.thr_plus_lo) * (1. - 1e-3);
     o.rp_up = guard_pow10(o.thr_plus_lo) * (1. + 1e-3);
     o.ninv = 1. / n;
-    o.np1 = n + 1.;
+    o.np1inv = 1. / (n + 1.);
     const double t2 = o.ninv * o.ninv;
     o.vsum2 = -(o.ninv * rim_fma(rim_fma(rim_fma(3., t2, -4.), t2, -14.), t2, 420.)) / 0.5040e4;
     o.lgam = rim_lgamma_pos(n);
@@ -145,9 +145,11 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     const double n = o.n;
     const double z = rim_div_by(x, n, o.ninv);
     const double eps = rim_div_by(n - x, n, o.ninv);
-    const double Z = rim_sqrt(eps * (1 + z));
-    // Z = sqrt(eps (1 + z)) with eps in [2^-53, 1) (x < n here): 1e-8 < Z < 1.42, n < 1e15 -> moderate operands
-    const double U = rim_div_moderate(1., n * Z * Z * Z);
+    // Z = sqrt(eps (1 + z)), U = 1 / (n Z^3) and factor = 1 / ((n + 1) sqrt(Z)) from one inverse fourth root
+    // (eps in [2^-53, 1) since x < n here: 1e-8 < Z < 1.42)
+    double Z, inv_z3, inv_sqrt_z;
+    rim_meissel_roots(eps * (1 + z), &Z, &inv_z3, &inv_sqrt_z);
+    const double U = o.ninv * inv_z3;
     const double t = z * z;
 
     // each coefficient row is folded into the Horner value in U as soon as it is formed (one row live at a time)
@@ -197,7 +199,7 @@ RIM_DEV double meissel_first(const LeungOrder &o, double x)
     v = rim_fma(v, U, ak);
     const double vsum1 = rim_div_by(U * v, 0.10321920e8, 1. / 0.10321920e8);
 
-    const double factor = rim_div_moderate(1., o.np1 * rim_sqrt(Z));
+    const double factor = o.np1inv * inv_sqrt_z;
 
     double exp_val;
     if (eps < 1e-4 && o.big_n) {
