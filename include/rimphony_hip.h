@@ -232,7 +232,8 @@ int rimphony_gamma_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const
 /* Unit seam: one leaf function of rimphony_amd/csrc/detmath.h over arrays, as the kernels evaluate it
  * (the parity contract is that gcc/x86-64 and hipcc/gfx950 give the same bits for these).
  * op: 0 exp, 1 log, 2 log10, 3 pow(x, y), 4 sqrt, 5 log10_region, 6 lgamma (x > 0), 7 sin, 8 cos,
- * 9 rim_div_by(x, y, 1/y), 10 cbrt (positive normal x).  d_y is only read by ops 3 and 9. */
+ * 9 rim_div_by(x, y, 1/y), 10 cbrt (positive normal x), 11 1/Gamma(x) (-8.5 < x < 9.5), 12 rim_third_powers(x)[(int) y],
+ * 13 x^(-1/4) (positive normal x), 14 rim_powexp_normal(x, y, -x/1000).  d_y is only read by ops 3, 9, 12 and 14. */
 int rimphony_detmath_batch_device(rimphony_ctx *ctx, int op, size_t n, const double *d_x, const double *d_y,
                                   double *d_out, void *stream);
 

@@ -81,13 +81,32 @@ static double ascending_series(double nu, double q, double sign)
 double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x > 0 */
 {
     const double h = 0.5 * x;
+#ifndef RIMO_LIBM
+    /* the four orders of the quasi-resonant elements: the deterministic flavour takes (x/2)^nu from one cube root and
+     * 1 / Gamma(1 + nu) as a constant, as the kernels do (rim_third_powers, detmath.h) */
+    static const double ORD[4] = { 2. / 3., -2. / 3., 1. / 3., -1. / 3. };
+    static const double RGAM[4] = { RIM_RGAMMA_5_3, RIM_RGAMMA_1_3, RIM_RGAMMA_4_3, RIM_RGAMMA_2_3 };
+    for (int j = 0; j < 4; j++)
+        if (nu == ORD[j]) {
+            double pref[4];
+            rim_third_powers(h, pref);
+            return (pref[j] * RGAM[j]) * ascending_series(nu, h * h, 1.);
+        }
+#endif
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, 1.);
 }
 
 double rimo_bessel_jnu(double nu, double x)  /* J_nu(x), x > 0, small x */
 {
     const double h = 0.5 * x;
+#ifndef RIMO_LIBM
+    /* the deterministic flavour multiplies by 1 / Gamma from the short-range series where it applies, as the kernels do */
+    const double z = nu + 1.;
+    const double rg = RIM_RGAMMA_NEAR(z) ? rim_rgamma_near(z) : 1. / rimo_gamma_real(z);
+    return m_pow(h, nu) * rg * ascending_series(nu, h * h, -1.);
+#else
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);
+#endif
 }
 
 double rimo_bessel_ynu(double nu, double x)  /* Y_nu(x) by reflection */

@@ -178,7 +178,8 @@ class Context:
         return np.array(list(hist), dtype=np.int64).reshape(8, 8)
 
     DETMATH_OPS = {"exp": 0, "log": 1, "log10": 2, "pow": 3, "sqrt": 4, "log10_region": 5, "lgamma": 6, "sin": 7, "cos": 8,
-                   "div_by": 9, "cbrt": 10}
+                   "div_by": 9, "cbrt": 10, "rgamma": 11, "third_powers": 12,
+                   "rqrt4": 13, "powexp": 14}
 
     def detmath_batch(self, op, x, y=None):
         """Unit seam: a leaf function of detmath.h evaluated on the device over host arrays."""

@@ -41,7 +41,13 @@ extern __shared__ unsigned long long rim_prof_lds[];      /* 32 words of dynamic
 #define RIM_HIT(idx) do { const unsigned long long rim_ex_ = __builtin_amdgcn_read_exec(); \
     if (__builtin_amdgcn_mbcnt_hi((unsigned) (rim_ex_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) rim_ex_, 0u)) == 0u) \
         __hip_atomic_fetch_add(&rim_prof_lds[idx], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+/* lanes (of the active ones) on which cond holds, summed per wave */
+#define RIM_LANES(idx, cond) do { const unsigned long long rim_ex_ = __builtin_amdgcn_read_exec(); \
+    const unsigned long long rim_b_ = __builtin_amdgcn_ballot_w64(cond); \
+    if (__builtin_amdgcn_mbcnt_hi((unsigned) (rim_ex_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) rim_ex_, 0u)) == 0u) \
+        __hip_atomic_fetch_add(&rim_prof_lds[idx], (unsigned long long) __builtin_popcountll(rim_b_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 #else
+#define RIM_LANES(idx, cond)
 #define RIM_PROF_T(t) const unsigned long long t = __builtin_readcyclecounter()
 #define RIM_PROF_ADD(idx, t) do { if ((threadIdx.x & 63) == 0) \
     __hip_atomic_fetch_add(&rim_prof_lds[idx], __builtin_readcyclecounter() - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
@@ -54,6 +60,7 @@ extern __shared__ unsigned long long rim_prof_lds[];      /* 32 words of dynamic
 #define RIM_PROF_ADD(idx, t)
 #define RIM_PROF_COUNT(idx, v)
 #define RIM_HIT(idx)
+#define RIM_LANES(idx, cond)
 #endif
 
 #define RIM_NAN (__builtin_nan(""))
@@ -546,6 +553,68 @@ RIM_FN double rim_cbrt_normal(double x)
     const double z0 = x * c;
     const double r = rim_fma(-(z0 * z0), z0, x);
     return rim_fma_k(r * c, 1. / 3., z0);
+}
+
+/* h^(2/3), h^(-2/3), h^(1/3), h^(-1/3) for h >= 0 (the prefactors (x/2)^nu of the four modified Bessel functions of a
+ * quasi-resonant Faraday sample, heyvaerts.rs:312-326,409-418) from ONE cube root and one division, where four
+ * powers take a double-double logarithm and four exponentials.  +0 gives {0, inf, 0, inf} as pow does; a negative or
+ * NaN argument NaN.  A few ulp (the squares); oracle (deterministic build) and kernels share it. */
+RIM_FN void rim_third_powers(double h, double out[4])
+{
+    double a;
+    if (h >= 2.2250738585072014e-308) a = rim_cbrt_normal(h);
+    else if (h > 0.) a = rim_cbrt_normal(h * 1.532495540865889e+54) * 8.673617379884035e-19;      /* 2^180, 2^-60 */
+    else a = (h == 0.) ? 0. : RIM_NAN;
+    const double ainv = 1. / a;
+    out[0] = a * a;
+    out[1] = ainv * ainv;
+    out[2] = a;
+    out[3] = ainv;
+}
+/* 1 / Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3, correctly rounded */
+#define RIM_RGAMMA_5_3 1.1077321674324725
+#define RIM_RGAMMA_1_3 0.3732821739073952
+#define RIM_RGAMMA_4_3 1.1198465217221858
+#define RIM_RGAMMA_2_3 0.7384881116216483
+
+/* 1 / Gamma(z) for -8.5 < z < 9.5, ~2 ulp (tests/test_detmath.py): z = m + z0 with m the nearest integer, the Taylor
+ * series 1 / Gamma(z0) = z0 S(z0) (|z0| <= 1/2, 20 terms), and the recurrence: m >= 1 gives S / ((z0 + 1) .. (z0 + m - 1)),
+ * m <= 0 gives z0 S (z0 - 1) .. (z0 + m) -- exactly 0 at the poles.  The J_nu prefactors of the Faraday elements
+ * ((x/2)^nu / Gamma(nu + 1), nu = +-sigma, +-(sigma - 1) with sigma < ~4) divide by a Gamma function per series; the
+ * shift-up-and-Stirling evaluation it replaces there took ~170 operations, this ~50. */
+#define RIM_RGAMMA_NEAR(z) ((z) > -8.5 && (z) < 9.5)
+RIM_FN double rim_rgamma_near(double z)
+{
+    const double m = __builtin_rint(z);
+    const double z0 = z - m;                       /* exact */
+    double s = 7.782263439905071e-12;
+    s = rim_fma_k(s, z0, 1.0434267116911005e-10);
+    s = rim_fma_k(s, z0, -1.18127457048702e-09);
+    s = rim_fma_k(s, z0, 5.002007644469223e-09);
+    s = rim_fma_k(s, z0, 6.116095104481416e-09);
+    s = rim_fma_k(s, z0, -2.056338416977607e-07);
+    s = rim_fma_k(s, z0, 1.133027231981696e-06);
+    s = rim_fma_k(s, z0, -1.2504934821426706e-06);
+    s = rim_fma_k(s, z0, -2.013485478078824e-05);
+    s = rim_fma_k(s, z0, 0.0001280502823881162);
+    s = rim_fma_k(s, z0, -0.00021524167411495098);
+    s = rim_fma_k(s, z0, -0.0011651675918590652);
+    s = rim_fma_k(s, z0, 0.0072189432466631);
+    s = rim_fma_k(s, z0, -0.009621971527876973);
+    s = rim_fma_k(s, z0, -0.04219773455554433);
+    s = rim_fma_k(s, z0, 0.16653861138229148);
+    s = rim_fma_k(s, z0, -0.04200263503409524);
+    s = rim_fma_k(s, z0, -0.6558780715202539);
+    s = rim_fma_k(s, z0, 0.5772156649015329);
+    s = rim_fma_k(s, z0, 1.0);       /* S(z0), S_0 .. S_19 */
+    if (m >= 1.) {
+        double p = 1.;
+        for (double k = 1.; k < m; k += 1.) p = p * (z0 + k);
+        return s / p;
+    }
+    double p = z0;
+    for (double k = -1.; k >= m; k -= 1.) p = p * (z0 + k);
+    return s * p;
 }
 
 /* ---- atan, acos (only the Meissel "second" expansion of the Bessel seam needs them) -------------- */

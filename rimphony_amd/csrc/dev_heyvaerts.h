@@ -37,6 +37,14 @@ RIM_DEV double gamma_real(double z)
     return rim_exp(rim_lgamma_stirling(w)) / prod;
 }
 
+// 1 / Gamma(z): the short-range series-and-recurrence evaluation where it applies (the orders of the J/Y branch lie
+// within a few units of 0), else through gamma_real
+RIM_DEV double rgamma_real(double z)
+{
+    if (RIM_RGAMMA_NEAR(z)) return rim_rgamma_near(z);
+    return 1. / gamma_real(z);
+}
+
 RIM_DEV double ascending_series(double nu, double q, double sign)
 {
     double term = 1., sum = 1.;
@@ -103,7 +111,7 @@ RIM_DEV double ascending_series_tab(const double *lrow, const double *row, doubl
 RIM_DEV double bessel_jnu(double nu, double x)
 {
     const double h = 0.5 * x;
-    return rim_pow_pos(h, nu) / gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);   // h >= 0 (x = sqrt(..))
+    return rim_pow_pos(h, nu) * rgamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);   // h >= 0 (x = sqrt(..))
 }
 
 RIM_DEV double bessel_ynu(double nu, double x)
@@ -146,7 +154,7 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
         else if (k < 4) { nu = -nu_y[w]; need = w == 0 || want_ym1; }
         else { nu = nu_y[w]; need = (w == 0 || want_ym1) && nu_y[w] != sigma - (double) w; }
         double v = 0.;
-        if (need) { RIM_HIT(29); v = rim_pow_from_log(lh, ll, nu) / gamma_real(nu + 1.) * ascending_series(nu, hsq, -1.); }   // = bessel_jnu(nu, x)
+        if (need) { RIM_HIT(29); v = rim_pow_from_log(lh, ll, nu) * rgamma_real(nu + 1.) * ascending_series(nu, hsq, -1.); }   // = bessel_jnu(nu, x)
         r[k] = v;
     }
     *js = r[0];
@@ -184,8 +192,8 @@ inline const double *hey_series_lds_table_host()
 }
 #endif
 
-// Per-task constants: Gamma(1 + nu) for nu = 2/3, -2/3, 1/3, -1/3, and the series divisor table.
-struct HeyConsts { double g_p23, g_m23, g_p13, g_m13; const double *tab; const double *ltab; };
+// Per-task constants: the series divisor table.
+struct HeyConsts { const double *tab; const double *ltab; };
 
 // series_tab: the global table; lds_tab: the wave's LDS copy of its head ([4][RIM_SERIES_LDS_ROW], filled by
 // hey_series_lds_fill) or, on the host, a table with that layout
@@ -194,29 +202,24 @@ RIM_DEV HeyConsts hey_consts(const double *series_tab, const double *lds_tab)
     HeyConsts c;
     c.tab = series_tab;
     c.ltab = lds_tab;
-    c.g_p23 = gamma_real(2. / 3. + 1.);
-    c.g_m23 = gamma_real(-2. / 3. + 1.);
-    c.g_p13 = gamma_real(1. / 3. + 1.);
-    c.g_m13 = gamma_real(-1. / 3. + 1.);
     return c;
 }
 
-// The four I_nu(x) of a quasi-resonant sample (nu = 2/3, -2/3, 1/3, -1/3): the same values as four bessel_i_g
-// calls, with the double-double log of x/2 that the four powers (x/2)^nu start from taken once.
+// The four I_nu(x) of a quasi-resonant sample (nu = 2/3, -2/3, 1/3, -1/3), I_nu = (x/2)^nu / Gamma(1 + nu) * series:
+// the four prefactors from one cube root (rim_third_powers), the four 1 / Gamma(1 + nu) as constants.
 RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
 {
     RIM_HIT(27);
     const double h = 0.5 * x;
     const double hsq = h * h;
-    double ll;
-    const double lh = rim_log_dd(h, &ll);
-    const double gam[4] = { hc.g_p23, hc.g_m23, hc.g_p13, hc.g_m13 };
+    double pref[4];
+    rim_third_powers(h, pref);
+    pref[0] *= RIM_RGAMMA_5_3; pref[1] *= RIM_RGAMMA_1_3; pref[2] *= RIM_RGAMMA_4_3; pref[3] *= RIM_RGAMMA_2_3;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma nounroll
 #endif
     for (int j = 0; j < 4; j++)
-        out[j] = rim_pow_from_log(lh, ll, hey_series_order(j)) / gam[j]
-            * ascending_series_tab(hc.ltab + j * RIM_SERIES_LDS_ROW, hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
+        out[j] = pref[j] * ascending_series_tab(hc.ltab + j * RIM_SERIES_LDS_ROW, hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
 }
 
 // Observer data of one Faraday coefficient (wave-uniform)

@@ -175,6 +175,11 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
         if (!so.small) c0 = leung_select_code(so.o[0], z, pos0);
         const int c1 = leung_select_code(so.o[1], z, pos1);
         RIM_PROF_ADD(3, t_sel);
+        RIM_LANES(30, true);
+        RIM_LANES(26, ((c0 | c1) & LSEL_DEBYE) != 0);
+        RIM_LANES(27, (c0 & LSEL_MEISSEL) != 0);
+        RIM_LANES(28, (c1 & LSEL_MEISSEL) != 0);
+        RIM_LANES(29, (c1 & LSEL_BLEND) != 0);
         // Debye for both orders in one go (they share everything but x - n), Meissel order by order
         RIM_PROF_T(t_deb);
         double deb0 = 0., deb1 = 0.;

@@ -333,7 +333,6 @@ struct HeyvaertsProblem {
         }
         __syncthreads();
         c.hc = hey_consts(a.series_tab, extra_lds);
-        c.hc.g_p23 = uni(c.hc.g_p23); c.hc.g_m23 = uni(c.hc.g_m23); c.hc.g_p13 = uni(c.hc.g_p13); c.hc.g_m13 = uni(c.hc.g_m13);
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     {
@@ -1863,6 +1862,10 @@ __global__ void detmath_kernel(int op, size_t n, const double *x, const double *
     case 8: rim_sincos(a, &t, &r); break;
     case 9: r = rim_div_by(a, b, 1. / b); break;
     case 10: r = rim_cbrt_normal(a); break;
+    case 11: r = rim_rgamma_near(a); break;
+    case 12: { double o4[4]; rim_third_powers(a, o4); const int j = (int) b; r = j == 0 ? o4[0] : j == 1 ? o4[1] : j == 2 ? o4[2] : o4[3]; break; }
+    case 13: r = rim_rqrt4_normal(a); break;
+    case 14: r = rim_powexp_normal(a, b, -a * 1e-3); break;
     default: r = RIM_NAN; break;
     }
     out[i] = r;
@@ -1871,7 +1874,7 @@ __global__ void detmath_kernel(int op, size_t n, const double *x, const double *
 extern "C" int rimphony_detmath_batch_device(rimphony_ctx *c, int op, size_t n, const double *d_x, const double *d_y,
                                              double *d_out, void *stream)
 {
-    if (!c || op < 0 || op > 10) return RIMPHONY_EINVAL;
+    if (!c || op < 0 || op > 14) return RIMPHONY_EINVAL;
     if (n == 0) return RIMPHONY_OK;
     if (!d_x || !d_out || ((op == 3 || op == 9) && !d_y)) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));

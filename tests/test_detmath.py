@@ -30,6 +30,11 @@ double t_pow_pos(double x,double y){return rim_pow_pos(x,y);}
 double t_pow_normal(double x,double y){return rim_pow_normal(x,y);}
 double t_div_by(double a,double b){return rim_div_by(a,b,1.0/b);}
 double t_cbrt(double x){return rim_cbrt_normal(x);}
+double t_rgamma(double x){return rim_rgamma_near(x);}
+double t_third(double x,double j){double o[4];rim_third_powers(x,o);return o[(int)j];}
+double t_rqrt4(double x){return rim_rqrt4_normal(x);}
+double t_powexp(double x,double y){return rim_powexp_normal(x,y,-x*1e-3);}
+void t_meissel_roots(double y,double *o){rim_meissel_roots(y,o,o+1,o+2);}
 '''
 
 
@@ -143,6 +148,50 @@ def test_cbrt(dm):
         assert dm.t_cbrt(k * k * k) == k
 
 
+def test_rgamma_third_powers_rqrt4_powexp(dm):
+    """The other lock-step leaf functions (detmath.h): 1 / Gamma on (-8.5, 9.5) -- a few ulp, exact zeros at the poles,
+    1 / (m - 1)! at the integers --, the four third powers, y^(-1/4) with the Meissel roots built on it, and x^y exp(e)."""
+    for n in ("t_rgamma", "t_rqrt4"):
+        getattr(dm, n).restype = ctypes.c_double
+        getattr(dm, n).argtypes = [ctypes.c_double]
+    for n in ("t_third", "t_powexp"):
+        getattr(dm, n).restype = ctypes.c_double
+        getattr(dm, n).argtypes = [ctypes.c_double] * 2
+    dm.t_meissel_roots.restype = None
+    dm.t_meissel_roots.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    mp.mp.prec = 200
+    rng = np.random.default_rng(10)
+    zs = rng.uniform(-8.4, 9.4, 3000)
+    zs = zs[np.abs(zs - np.rint(zs)) > 1e-3]            # relative accuracy next to the zeros is checked separately
+    assert worst(dm.t_rgamma, mp.rgamma, zs) < 4.0
+    for m in range(-8, 1):
+        assert dm.t_rgamma(float(m)) == 0.
+        z = m + 1e-9
+        assert abs(dm.t_rgamma(z) / float(mp.rgamma(mp.mpf(z))) - 1.) < 1e-14
+    for m in range(1, 10):
+        assert abs(dm.t_rgamma(float(m)) * math.factorial(m - 1) - 1.) < 5e-16
+    hs = np.concatenate([np.exp(rng.uniform(-700., 2., 2000)), [5e-324, 1e-310, 2.2250738585072014e-308]])
+    for j, e in enumerate((mp.mpf(2) / 3, -mp.mpf(2) / 3, mp.mpf(1) / 3, -mp.mpf(1) / 3)):
+        assert worst(lambda x: dm.t_third(x, float(j)), lambda x: x ** e, hs) < 3.0
+    assert [dm.t_third(0., float(j)) for j in range(4)] == [0., math.inf, 0., math.inf]
+    assert all(math.isnan(dm.t_third(-1., float(j))) for j in range(4))
+    ys = np.exp(rng.uniform(math.log(1e-16), math.log(2.), 3000))
+    assert worst(dm.t_rqrt4, lambda y: y ** (-mp.mpf(1) / 4), ys) < 1.0
+    o = (ctypes.c_double * 3)()
+    wz = wu = wf = 0.
+    for y in ys[:1000]:
+        dm.t_meissel_roots(float(y), o)
+        ym = mp.mpf(float(y))
+        wz = max(wz, ulp_err(o[0], mp.sqrt(ym)))
+        wu = max(wu, ulp_err(o[1], ym ** (-mp.mpf(3) / 2)))
+        wf = max(wf, ulp_err(o[2], ym ** (-mp.mpf(1) / 4)))
+    assert wz <= 1.0 and wu < 12.0 and wf < 1.0, (wz, wu, wf)       # 1 / Z^3 = w^6 only scales the small V_n sum
+    xs, ps = np.exp(rng.uniform(0., 27., 2000)), rng.uniform(-8., -1., 2000)
+    w = max(ulp_err(dm.t_powexp(float(x), float(p)), mp.mpf(float(x)) ** mp.mpf(float(p)) * mp.exp(mp.mpf(float(-x * 1e-3))))
+            for x, p in zip(xs, ps) if float(x) ** float(p) * math.exp(-x * 1e-3) > 1e-300)       # e = the rounded -x/1000 the C side passes
+    assert w < 1.5, w
+
+
 def test_log10_region(dm):
     """The plain-double log10 of the Bessel region variable: a few ulp (<= 4) on (0, 1], its whole domain."""
     dm.t_log10_region.restype = ctypes.c_double
@@ -211,6 +260,15 @@ def test_leaf_functions_same_bits_on_gpu(dm):
     assert same(ctx.detmath_batch("div_by", a, b), a / b)
     xc = np.concatenate([np.exp(rng.uniform(-708., 709., 20000)), 30. * np.exp(rng.uniform(0., 34.5, 20000))])
     assert same(ctx.detmath_batch("cbrt", xc), cpu("t_cbrt", xc))
+    zg = np.concatenate([rng.uniform(-8.49, 9.49, 20000), np.arange(-8., 10.), np.arange(-8., 10.) + 1e-12])
+    assert same(ctx.detmath_batch("rgamma", zg), cpu("t_rgamma", zg))
+    ht = np.concatenate([np.exp(rng.uniform(-745., 3., 20000)), [0., 5e-324, 1e-310, -1., np.nan]])
+    jt = np.floor(rng.random(len(ht)) * 4.)
+    assert same(ctx.detmath_batch("third_powers", ht, jt), cpu("t_third", ht, jt))
+    yq = np.exp(rng.uniform(-708., 709., 20000))
+    assert same(ctx.detmath_batch("rqrt4", yq), cpu("t_rqrt4", yq))
+    xp, yp = np.exp(rng.uniform(0., 30., 20000)), rng.uniform(-9., 9., 20000)
+    assert same(ctx.detmath_batch("powexp", xp, yp), cpu("t_powexp", xp, yp))
     ctx.close()
 
 

@@ -60,3 +60,38 @@ extern "C" __global__ void k_calc_f_##kind(const double *in, double *out) { Dist
 extern "C" __global__ void k_calc_fd_##kind(const double *in, double *out) { DistParams d; dist_of<kind>(in, d); double g, c; \
     calc_f_derivatives<kind, 0>(d, in[threadIdx.x], in[64 + threadIdx.x], g, c); out[threadIdx.x] = g; out[64 + threadIdx.x] = c; }
 KF(0) KF(1) KF(2) KF(3)
+
+// ---- Faraday leaf functions ----
+#include "dev_heyvaerts.h"
+__device__ HeyPoint pt_of(const double *in)
+{
+    HeyPoint pt;
+    pt.s = in[210]; pt.sin_th = in[211]; pt.cos_th = in[212]; pt.sigma0 = in[213]; pt.sigma0_sq = in[214]; pt.stokes = (int) in[215];
+    return pt;
+}
+extern "C" __global__ void k_fill_coord(const double *in, double *out)
+{
+    const HeyCoord c = fill_coord_vars(pt_of(in), in[threadIdx.x], in[64 + threadIdx.x]);
+    out[threadIdx.x] = c.x + c.gamma + c.mu;
+}
+#define KH(kind) \
+extern "C" __global__ void k_h_nr_##kind(const double *in, double *out) { DistParams d; dist_of<kind>(in, d); const HeyPoint pt = pt_of(in); \
+    HeyCoord c; c.sigma = in[threadIdx.x]; c.pomega = in[64 + threadIdx.x]; c.x = in[128 + threadIdx.x]; c.gamma = in[256 + threadIdx.x]; c.mu = in[320 + threadIdx.x]; \
+    out[threadIdx.x] = h_nr_element<kind>(pt, d, c); } \
+extern "C" __global__ void k_f_nr_##kind(const double *in, double *out) { DistParams d; dist_of<kind>(in, d); const HeyPoint pt = pt_of(in); \
+    HeyCoord c; c.sigma = in[threadIdx.x]; c.pomega = in[64 + threadIdx.x]; c.x = in[128 + threadIdx.x]; c.gamma = in[256 + threadIdx.x]; c.mu = in[320 + threadIdx.x]; \
+    out[threadIdx.x] = f_nr_element<kind>(pt, d, c); } \
+extern "C" __global__ void k_dfdsigma_##kind(const double *in, double *out) { DistParams d; dist_of<kind>(in, d); const HeyPoint pt = pt_of(in); \
+    HeyCoord c; c.sigma = in[threadIdx.x]; c.pomega = in[64 + threadIdx.x]; c.x = in[128 + threadIdx.x]; c.gamma = in[256 + threadIdx.x]; c.mu = in[320 + threadIdx.x]; \
+    out[threadIdx.x] = dfdsigma<kind>(pt, d, c); }
+KH(0) KH(1) KH(2)
+extern "C" __global__ void k_nr_common(const double *in, double *out)
+{
+    HeyCoord c; c.sigma = in[threadIdx.x]; c.pomega = in[64 + threadIdx.x]; c.x = in[128 + threadIdx.x]; c.gamma = 0; c.mu = 0;
+    double a1, a2, xa1p, ssq, xsq;
+    nr_common(c, a1, a2, xa1p, ssq, xsq);
+    out[threadIdx.x] = a1 + a2 + xa1p + ssq + xsq;
+}
+K(pow15, rim_pow15(a))
+K(pow25, rim_pow25(a))
+K(full_div_same_divisor3, a / c + b / c + (a * b) / c)

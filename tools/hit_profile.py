@@ -27,7 +27,8 @@ names = {0: "integrand pass", 1: "  joint first application", 2: "qag_pick argma
          9: "  log branch", 10: "exp_factor |e| < 1e-3", 11: "exp_factor early zero", 12: "exp_factor |e| > 690", 13: "exp_factor exp_bounded",
          14: "beta < 0.1", 15: "beta >= 0.1", 16: "miller recurrence", 17: "select: x > n side", 18: "select: blend zone",
          19: "calc_f inside limits", 20: "calc_f_derivatives inside limits", 21: "request setup (pair)", 22: "integral complete",
-         24: "emission f_term", 25: "absorption f_term"}
+         24: "emission f_term", 25: "absorption f_term", 30: "LANES active in the Bessel pair", 26: "LANES needing Debye (either order)",
+         27: "LANES needing Meissel, order n", 28: "LANES needing Meissel, order n+1", 29: "LANES in the blend zone (order n+1)"}
 if faraday:
     names = {0: "integrand pass", 1: "  joint first application", 2: "qag_pick argmax (size > 2)", 22: "integral complete",
              25: "non-resonant element pass", 26: "quasi-resonant element pass", 27: "  I_{+-1/3,2/3} branch executed (bessel_i_g4)",
