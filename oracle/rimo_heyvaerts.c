@@ -78,6 +78,27 @@ static double ascending_series(double nu, double q, double sign)
     return sum;
 }
 
+#ifndef RIMO_LIBM
+/* the same series for the four fixed orders of the quasi-resonant elements as the kernels sum it (dev_heyvaerts.h
+ * ascending_series_tab): each term the previous one times q times the rounded reciprocal of k (k + nu), two terms
+ * per convergence test */
+static double ascending_series_pairs(double nu, double q)
+{
+    double term = 1., sum = 1.;
+    int k;
+    for (k = 1; k <= 500; k += 2) {
+        const double c1 = 1. / (k * (k + nu)), c2 = 1. / ((k + 1) * ((k + 1) + nu));
+        term = term * (q * c1);
+        sum = sum + term;
+        term = term * (q * c2);
+        sum = sum + term;
+        if (m_fabs(term) < 1e-17 * m_fabs(sum)) break;
+    }
+    if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) (k <= 500 ? k + 1 : 500); t_ctr->hey_series_calls += 1; }
+    return sum;
+}
+#endif
+
 double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x > 0 */
 {
     const double h = 0.5 * x;
@@ -90,7 +111,7 @@ double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x 
         if (nu == ORD[j]) {
             double pref[4];
             rim_third_powers(h, pref);
-            return (pref[j] * RGAM[j]) * ascending_series(nu, h * h, 1.);
+            return (pref[j] * RGAM[j]) * ascending_series_pairs(nu, h * h);
         }
 #endif
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, 1.);

@@ -76,32 +76,39 @@ RIM_DEV void hey_series_table_entry(int j, int k, double *entry)
     entry[1] = 1. / b;
 }
 
-// The first RIM_SERIES_LDS entries of each order's row are also kept in the wave's LDS (lrow; layout [0 .. RIM_SERIES_LDS + 1]
-// pairs, entry 0 unused, the last one padding for the one-term-ahead read): a term of the series is 8 vector instructions,
-// and one global load per term with a full wait in between left the wave stalled for most of each iteration (the
-// Faraday kernel was 75 % VALU-busy).  LDS reads are prefetched one term ahead.  Series longer than that (rare: g
-// close to 10) continue from the global table.  Host builds pass the same array for both.
+// The first RIM_SERIES_LDS entries of each order's row are also kept in the wave's LDS (lrow; layout [0 .. RIM_SERIES_LDS + 2]
+// pairs, entry 0 unused, the last two padding for the one-pair-ahead read): one global load per term with a full wait in
+// between left the wave stalled for most of each iteration (the Faraday kernel was 75 % VALU-busy).  LDS reads are
+// prefetched one pair of terms ahead.  Series longer than that (rare: g close to 10) continue from the global table.
+// Host builds pass a table with the same layout.
 #define RIM_SERIES_LDS 20
-#define RIM_SERIES_LDS_ROW (2 * (RIM_SERIES_LDS + 2))
+#define RIM_SERIES_LDS_ROW (2 * (RIM_SERIES_LDS + 3))
 
 RIM_DEV double ascending_series_tab(const double *lrow, const double *row, double q, double sign)
 {
+    // Terms are added two at a time, each the previous one times q times the tabulated reciprocal of k (k + nu), and the
+    // series ends after the first PAIR whose second term is below 1e-17 of the sum (the deterministic oracle does the
+    // same; the literal one divides term by term and tests after each).  4 vector instructions per term instead of 7.
     double term = 1., sum = 1.;
     const double sq = sign * q;
-    double b = lrow[2], binv = lrow[3];
+    double c1 = lrow[3], c2 = lrow[5];
     int k = 1;
-    for (; k <= RIM_SERIES_LDS; k++) {
+    for (; k <= RIM_SERIES_LDS; k += 2) {
         RIM_HIT(31);
-        const double bn = lrow[2 * k + 2], bninv = lrow[2 * k + 3];      // next term's divisor, in flight during this term
-        term = term * rim_div_by(sq, b, binv);
+        const double n1 = lrow[2 * k + 5], n2 = lrow[2 * k + 7];      // the next pair's reciprocals, in flight during this pair
+        term = term * (sq * c1);
+        sum = sum + term;
+        term = term * (sq * c2);
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) return sum;
-        b = bn;
-        binv = bninv;
+        c1 = n1;
+        c2 = n2;
     }
-    for (; k <= RIM_SERIES_TERMS; k++) {
+    for (; k <= RIM_SERIES_TERMS; k += 2) {
         RIM_HIT(31);
-        term = term * rim_div_by(sq, row[2 * k], row[2 * k + 1]);
+        term = term * (sq * row[2 * k + 1]);
+        sum = sum + term;
+        term = term * (sq * row[2 * k + 3]);
         sum = sum + term;
         if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
     }

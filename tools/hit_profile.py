@@ -33,7 +33,7 @@ if faraday:
     names = {0: "integrand pass", 1: "  joint first application", 2: "qag_pick argmax (size > 2)", 22: "integral complete",
              25: "non-resonant element pass", 26: "quasi-resonant element pass", 27: "  I_{+-1/3,2/3} branch executed (bessel_i_g4)",
              28: "  J/Y branch executed (bessel_jy_set)", 29: "    J/Y jobs run (of 6 per execution)", 24: "    gamma_real shift-up iterations",
-             30: "    real-order series term iterations", 31: "  fixed-order (table) series term iterations"}
+             30: "    real-order series term iterations", 31: "  fixed-order (table) series iterations (two terms each)"}
     print("faraday kernel ms %.1f  samples %d passes %d  hits[0] %d" % (ctx.last_faraday_ms(), w["faraday_samples"], w["faraday_passes"], c[0]))
 else:
     print("kernel ms %.1f  samples %d passes %d  hits[0] %d" % (ctx.last_symphony_ms(), w["samples"], w["passes"], c[0]))
