@@ -268,13 +268,60 @@ static double f_nr_element(const hey_state *st)
     return -2. * RIM_PI * INVERSE_C * z * st->pomega * dfds;
 }
 
+/* The deterministic flavour of the two non-resonant elements, operation for operation what the kernels evaluate
+ * (dev_heyvaerts.h nr_common / h_nr_element / f_nr_element): every division by a power of sigma^2 - x^2 as a product of
+ * powers of u = 1 / sqrt(sigma^2 - x^2).  h_nr_element / f_nr_element above stay the literal restatement (the libm
+ * flavour runs them; tools/check_literals.py compares both forms with heyvaerts.rs:379-394, 453-468). */
+static void nr_common_det(const hey_state *st, double *a1, double *a2, double *xa1p, double *x_sq, double *u, double *u2)
+{
+    const double s_sq = st->sigma * st->sigma;
+    *x_sq = st->x * st->x;
+    *u = 1. / m_sqrt(s_sq - *x_sq);
+    *u2 = *u * *u;
+    const double ratio = s_sq * *u2;
+    *a1 = 1. / 8. - 5. / 24. * ratio;
+    *a2 = 3. / 128. - 77. / 576. * ratio + 385. / 3456. * (ratio * ratio);
+    *xa1p = -5. / 12. * (s_sq * *x_sq) * (*u2 * *u2);
+}
+
+static double h_nr_element_det(const hey_state *st)
+{
+    double a1, a2, xa1p, x_sq, u, u2;
+    nr_common_det(st, &a1, &a2, &xa1p, &x_sq, &u, &u2);
+    const double u3 = u2 * u;
+    const double t1 = (6. * a2 - a1 * a1 + xa1p) * u + a1 * x_sq * u3
+        - (x_sq * x_sq) * (u3 * u2) * 0.125;
+    const double t2 = (6. * a2 - a1 * a1) * u3;
+    const double u1 = 2. * t1 - st->sigma0_sq * t2;
+    const double dfds = dfdsigma(st);
+    return RIM_PI * INVERSE_C * u1 * dfds;
+}
+
+static double f_nr_element_det(const hey_state *st)
+{
+    double a1, a2, xa1p, x_sq, u, u2;
+    nr_common_det(st, &a1, &a2, &xa1p, &x_sq, &u, &u2);
+    const double z =
+        0.5 * x_sq * (u2 * u)
+        + (6. * a2 + xa1p - a1 * a1) * u2
+        + 1.5 * a1 * x_sq * (u2 * u2);
+    const double dfds = dfdsigma(st);
+    return -2. * RIM_PI * INVERSE_C * z * st->pomega * dfds;
+}
+
 /* inner integrands: the integration variable is sigma (NR) or pomega (QR) */
 static double nr_inner_cb(double sigma, void *ctx)
 {
     hey_state *st = (hey_state *) ctx;
     fill_coord_vars(st, sigma, st->fixed);
     if (st->c) { st->c->integrand_evals++; st->c->hey_nr_samples++; }
+#ifdef RIMO_LIBM
+    (void) h_nr_element_det; (void) f_nr_element_det;
     return st->stokes == RIMO_STOKES_Q ? h_nr_element(st) : f_nr_element(st);
+#else
+    (void) h_nr_element; (void) f_nr_element;
+    return st->stokes == RIMO_STOKES_Q ? h_nr_element_det(st) : f_nr_element_det(st);
+#endif
 }
 
 static double qr_inner_cb(double pomega, void *ctx)

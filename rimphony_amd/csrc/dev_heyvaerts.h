@@ -301,25 +301,30 @@ RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
     return RIM_INVERSE_C * (t1 + t2 + t3) * dfds;
 }
 
-RIM_DEV void nr_common(const HeyCoord &c, double &a1, double &a2, double &xa1p, double &ssqmxsq, double &x_sq)
+// The non-resonant elements (heyvaerts.rs:379-394, 453-468) divide by the powers 1/2, 1, 3/2, 2 and 5/2 of
+// sigma^2 - x^2 eleven times between them.  Here every one is a product of powers of u = 1 / sqrt(sigma^2 - x^2): one
+// square root and one division per sample (the deterministic oracle does the same; the literal one divides).
+RIM_DEV void nr_common(const HeyCoord &c, double &a1, double &a2, double &xa1p, double &x_sq, double &u, double &u2)
 {
     const double s_sq = c.sigma * c.sigma;
     x_sq = c.x * c.x;
-    ssqmxsq = s_sq - x_sq;
-    const double ratio = s_sq / ssqmxsq;
-    a1 = 1. / 8. - 5. / 24. * s_sq / ssqmxsq;
-    a2 = 3. / 128. - 77. / 576. * s_sq / ssqmxsq + 385. / 3456. * (ratio * ratio);
-    xa1p = -5. / 12. * s_sq * x_sq / (ssqmxsq * ssqmxsq);
+    u = 1. / rim_sqrt(s_sq - x_sq);
+    u2 = u * u;
+    const double ratio = s_sq * u2;
+    a1 = 1. / 8. - 5. / 24. * ratio;
+    a2 = 3. / 128. - 77. / 576. * ratio + 385. / 3456. * (ratio * ratio);
+    xa1p = -5. / 12. * (s_sq * x_sq) * (u2 * u2);
 }
 
 template <int KIND>
 RIM_DEV double h_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
 {
-    double a1, a2, xa1p, ssqmxsq, x_sq;
-    nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
-    const double t1 = (6. * a2 - a1 * a1 + xa1p) / rim_sqrt(ssqmxsq) + a1 * x_sq / rim_pow15(ssqmxsq)
-        - (x_sq * x_sq) / rim_pow25(ssqmxsq) / 8.;
-    const double t2 = (6. * a2 - a1 * a1) / rim_pow15(ssqmxsq);
+    double a1, a2, xa1p, x_sq, u, u2;
+    nr_common(c, a1, a2, xa1p, x_sq, u, u2);
+    const double u3 = u2 * u;
+    const double t1 = (6. * a2 - a1 * a1 + xa1p) * u + a1 * x_sq * u3
+        - (x_sq * x_sq) * (u3 * u2) * 0.125;
+    const double t2 = (6. * a2 - a1 * a1) * u3;
     const double u1 = 2. * t1 - pt.sigma0_sq * t2;
     const double dfds = dfdsigma<KIND>(pt, d, c);
     return RIM_PI * RIM_INVERSE_C * u1 * dfds;
@@ -350,12 +355,12 @@ RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
 template <int KIND>
 RIM_DEV double f_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
 {
-    double a1, a2, xa1p, ssqmxsq, x_sq;
-    nr_common(c, a1, a2, xa1p, ssqmxsq, x_sq);
+    double a1, a2, xa1p, x_sq, u, u2;
+    nr_common(c, a1, a2, xa1p, x_sq, u, u2);
     const double z =
-        0.5 * x_sq / rim_pow15(ssqmxsq)
-        + (6. * a2 + xa1p - a1 * a1) / ssqmxsq
-        + 1.5 * a1 * x_sq / (ssqmxsq * ssqmxsq);
+        0.5 * x_sq * (u2 * u)
+        + (6. * a2 + xa1p - a1 * a1) * u2
+        + 1.5 * a1 * x_sq * (u2 * u2);
     const double dfds = dfdsigma<KIND>(pt, d, c);
     return -2. * RIM_PI * RIM_INVERSE_C * z * c.pomega * dfds;
 }

@@ -344,8 +344,8 @@ def main():
     for fn, stop in (("h_nr_element", "template <int KIND>\nRIM_DEV double f_qr_element"), ("f_nr_element", "// The inner integrand of either regime")):
         ref, _ = run_rust(fn)
         body = between(dh, "RIM_DEV double %s(" % fn, stop)
-        body = re.sub(r"double a1, a2, xa1p, ssqmxsq, x_sq;\s*nr_common\([^;]*;", "", body)
-        e = run_dev(body + " ", "{", "\n}\n" if "\n}\n" in body else "}", extra={k: common[k] for k in ("a1", "a2", "xa1p", "ssqmxsq", "x_sq")})
+        body = re.sub(r"double a1, a2, xa1p, x_sq, u, u2;\s*nr_common\([^;]*;", "", body)
+        e = run_dev(body + " ", "{", "\n}\n" if "\n}\n" in body else "}", extra={k: common[k] for k in ("a1", "a2", "xa1p", "x_sq", "u", "u2")})
         same("%s (heyvaerts.rs:379-394 / 453-468)            vs dev_heyvaerts.h" % fn, e["RESULT"], ref)
         body = between(oh, "static double %s(const hey_state *st)" % fn, "\n}\n")
         e = run_dev(body + " ", "{", "return" if False else "\n", extra=None) if False else run_dev(oh, "static double %s(const hey_state *st)" % fn, "\n}\n")
