@@ -172,6 +172,8 @@ typedef struct {
     int hey_max_steps;      /* 4096   the same for heyvaerts.rs:102,134,161  */
 } rimo_tuning;
 void rimo_set_tuning(const rimo_tuning *t);
+/* Investigation knob (tools/nan_pattern.py only): count Symphony integrand samples below DBL_MIN as 0.  Default off. */
+void rimo_set_flush_subnormal_samples(int on);
 void rimo_get_tuning(rimo_tuning *t);
 
 #ifdef __cplusplus

@@ -85,10 +85,16 @@ static double gamma_integrand(sym_state *st, double gamma, double n)
     return gamma * gamma * pol_term * f_term;
 }
 
+/* investigation knob (tools/nan_pattern.py): integrand samples in the subnormal range count as 0 */
+static int g_flush_subnormal_samples = 0;
+void rimo_set_flush_subnormal_samples(int on) { g_flush_subnormal_samples = on; }
+
 static double gamma_integrand_cb(double g, void *ctx)
 {
     sym_state *st = (sym_state *) ctx;
-    return gamma_integrand(st, g, st->cur_n);
+    const double v = gamma_integrand(st, g, st->cur_n);
+    if (g_flush_subnormal_samples && m_fabs(v) < RIM_DBL_MIN) return 0.;
+    return v;
 }
 
 static double gamma_integral(sym_state *st, double n)
