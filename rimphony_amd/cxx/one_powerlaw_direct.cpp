@@ -22,5 +22,26 @@ int main()
     const double ndg = (ppd.calc_f(*ctx, g + eps, cx) - f0) / eps, ndc = (ppd.calc_f(*ctx, g, cx + eps) - f0) / eps;
     std::printf("dfdg %.10e (numeric %.10e)  dfdcx %.10e (numeric %.10e)\n", d[0], ndg, d[1], ndc);
     const bool deriv_ok = std::fabs((d[0] - ndg) / ndg) < 1e-4 && std::fabs((d[1] - ndc) / ndc) < 1e-4;
+    // the batched entries: one context, the multi-device entry over {that context} (degenerate sharding), work counters
+    std::vector<double> s, th;
+    std::vector<std::vector<double>> par(4);
+    for (int i = 0; i < 24; i++) {
+        s.push_back(3. + 7. * i); th.push_back(0.2 + 0.05 * i);
+        par[0].push_back(2.2 + 0.05 * i); par[1].push_back(1.); par[2].push_back(1e12); par[3].push_back(1e10);
+    }
+    std::vector<int32_t> st;
+    std::vector<uint64_t> work;
+    const auto one = BatchCalculator(ctx, RIMPHONY_POWER_LAW).compute(s, th, par, 0x0f, &st, &work);
+    const auto multi = BatchCalculator::compute_multi({ctx}, RIMPHONY_POWER_LAW, s, th, par, 0x0f);
+    bool batch_ok = true;
+    for (size_t i = 0; i < one.size(); i++) {
+        const bool selected = (i % 8) < 4;
+        batch_ok = batch_ok && (selected ? (one[i] == multi[i] && std::isfinite(one[i]) && work[i] > 0) : (std::isnan(one[i]) && work[i] == 0));
+    }
+    bool threw = false;
+    try { BatchCalculator(ctx, RIMPHONY_POWER_LAW).compute(s, th, {par[0]}, 0x01); } catch (const std::runtime_error &) { threw = true; }
+    std::printf("batch entries: %s, misuse throws: %s, device shared with another context: %s\n", batch_ok ? "ok" : "MISMATCH",
+                threw ? "yes" : "NO", ctx->shared_mode() ? "yes" : "no");
+    if (!batch_ok || !threw) return 1;
     return std::fabs(ji / 2.64399749412774e-21 - 1.) < 1e-3 && std::fabs(rho_q - 1.8e-9) < 0.05e-9 && deriv_ok ? 0 : 1;
 }

@@ -40,9 +40,15 @@ constexpr double ELECTRON_CHARGE = 4.80320680e-10;
 enum class Stokes { I = 0, Q = 1, V = 2 };
 enum class Coefficient { Emission = 0, Absorption = 1, Faraday = 2 };
 
+enum class Precision { F64 = RIMPHONY_PRECISION_F64, F32Integrand = RIMPHONY_PRECISION_F32_INTEGRAND };
+
 inline void check(int rc, const char *what)
 {
-    if (rc != RIMPHONY_OK) throw std::runtime_error(std::string(what) + ": " + rimphony_strerror(rc));
+    if (rc == RIMPHONY_OK) return;
+    std::string msg = std::string(what) + ": " + rimphony_strerror(rc);
+    const char *detail = rimphony_last_error();          // the HIP call that failed, if any (thread-local)
+    if (detail && *detail) msg += std::string(" -- ") + detail;
+    throw std::runtime_error(msg);
 }
 
 class Context {
@@ -52,6 +58,9 @@ public:
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     rimphony_ctx *get() const { return ctx_; }
+    // true when another context (this process or another) already owned the device at creation: the persistent grids are
+    // then a quarter of the device and the cooperative tail is off (include/rimphony_hip.h, "context")
+    bool shared_mode() const { return rimphony_ctx_shared_mode(ctx_) != 0; }
 private:
     rimphony_ctx *ctx_ = nullptr;
 };
@@ -70,25 +79,57 @@ public:
     {
         if (rimphony_dist_nparams(kind_) < 0) throw std::runtime_error("unknown distribution kind");
     }
+    // status: optional [n][8] RIMPHONY_ST_* words; work: optional [n][8] integrand samples spent per coefficient
     std::vector<double> compute(const std::vector<double> &s, const std::vector<double> &theta,
                                 const std::vector<std::vector<double>> &params, uint32_t mask = RIMPHONY_SLOTS_ALL,
-                                std::vector<int32_t> *status = nullptr) const
+                                std::vector<int32_t> *status = nullptr, std::vector<uint64_t> *work = nullptr,
+                                Precision precision = Precision::F64) const
     {
         const size_t n = s.size();
-        if (theta.size() != n || static_cast<int>(params.size()) != rimphony_dist_nparams(kind_))
+        const std::vector<const double *> pp = columns(kind_, n, theta, params);
+        std::vector<double> out(n * 8, std::numeric_limits<double>::quiet_NaN());
+        if (status) status->assign(n * 8, 0);
+        if (work) work->assign(n * 8, 0);
+        check(rimphony_batch_compute_ex(ctx_->get(), kind_, n, s.data(), theta.data(), pp.data(), mask,
+                                        static_cast<int>(precision), out.data(), status ? status->data() : nullptr,
+                                        work ? work->data() : nullptr), "rimphony_batch_compute_ex");
+        return out;
+    }
+    // The same table from several devices: row i is evaluated by contexts[i mod N] (one host thread per context) and
+    // lands in row i -- the table does not depend on N.
+    static std::vector<double> compute_multi(const std::vector<std::shared_ptr<Context>> &contexts, int dist_kind,
+                                             const std::vector<double> &s, const std::vector<double> &theta,
+                                             const std::vector<std::vector<double>> &params,
+                                             uint32_t mask = RIMPHONY_SLOTS_ALL, std::vector<int32_t> *status = nullptr,
+                                             std::vector<uint64_t> *work = nullptr, Precision precision = Precision::F64)
+    {
+        const size_t n = s.size();
+        const std::vector<const double *> pp = columns(dist_kind, n, theta, params);
+        std::vector<rimphony_ctx *> raw;
+        for (const auto &c : contexts) raw.push_back(c->get());
+        std::vector<double> out(n * 8, std::numeric_limits<double>::quiet_NaN());
+        if (status) status->assign(n * 8, 0);
+        if (work) work->assign(n * 8, 0);
+        check(rimphony_batch_compute_multi(raw.data(), static_cast<int>(raw.size()), dist_kind, n, s.data(), theta.data(),
+                                           pp.data(), mask, static_cast<int>(precision), out.data(),
+                                           status ? status->data() : nullptr, work ? work->data() : nullptr),
+              "rimphony_batch_compute_multi");
+        return out;
+    }
+private:
+    static std::vector<const double *> columns(int kind, size_t n, const std::vector<double> &theta,
+                                               const std::vector<std::vector<double>> &params)
+    {
+        if (rimphony_dist_nparams(kind) < 0) throw std::runtime_error("unknown distribution kind");
+        if (theta.size() != n || static_cast<int>(params.size()) != rimphony_dist_nparams(kind))
             throw std::runtime_error("compute: array shapes do not match");
         std::vector<const double *> pp;
         for (const auto &p : params) {
             if (p.size() != n) throw std::runtime_error("compute: parameter array length");
             pp.push_back(p.data());
         }
-        std::vector<double> out(n * 8, std::numeric_limits<double>::quiet_NaN());
-        if (status) status->assign(n * 8, 0);
-        check(rimphony_batch_compute(ctx_->get(), kind_, n, s.data(), theta.data(), pp.data(), mask, out.data(),
-                                     status ? status->data() : nullptr), "rimphony_batch_compute");
-        return out;
+        return pp;
     }
-private:
     std::shared_ptr<Context> ctx_;
     int kind_;
 };
