@@ -269,15 +269,21 @@ __device__ __forceinline__ void sym_eval_pair(const SymPoint &pt, const DistPara
     const int lane = g.lane;
     RIM_HIT(21);
     RIM_PROF_T(t_setup);
-    // ---- setup: every lane computes the data of its half's request, lanes 0 and 32 file them in LDS ----
+    // ---- setup: every lane computes data of its half's request -- even lanes the order record of n, odd lanes that of
+    // n + 1 (one leung_order per lane instead of two: the same values as sym_order, half the instructions) --, and
+    // lanes 0, 1, 32, 33 file them in LDS ----
     const bool second = g.half != 0 && have1;
     const double n_l = second ? n1 : n0;
-    LeungOrder ord_tmp[2];
-    const SymOrder so_l = sym_order(n_l, ord_tmp);
+    const double n_mine = (lane & 1) ? n_l + 1. : n_l;
+    LeungOrder ord_mine = LeungOrder();
+    if (!(n_mine < 30.)) ord_mine = leung_order(n_mine);
+    SymOrder so_l;
+    so_l.small = n_l < 30.;
+    so_l.np1_small = (n_l + 1.) < 30.;
+    so_l.dj_nan = n_l >= 1e15;
     const GammaLimits L = gamma_limits(pt, n_l, second ? lobe1 : lobe0);
     wv_sync();                       // nobody is still reading the previous requests' records
-    if (lane == 0) { qpark->ord[0] = ord_tmp[0]; qpark->ord[1] = ord_tmp[1]; }
-    if (lane == 32) { qpark->ord[2] = ord_tmp[0]; qpark->ord[3] = ord_tmp[1]; }
+    if ((lane & 30) == 0) qpark->ord[(lane >> 4) | (lane & 1)] = ord_mine;          // lanes 0, 1, 32, 33 -> records 0, 1, 2, 3
     wv_sync();
     const double a0 = readlane_d(L.g0, 0), b0 = readlane_d(L.g1, 0);
     const double a1 = readlane_d(L.g0, 32), b1 = readlane_d(L.g1, 32);
