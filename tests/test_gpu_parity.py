@@ -129,6 +129,39 @@ def test_gamma_integrand_bit_exact(gpu_ctx, oracle, kind):
         report_mismatch("gamma_integrand kind %d" % kind, got, ref, lambda i: (par, s, th, coeff, stokes, n[i], g[i]))
 
 
+def test_integrand_with_bessel_values_next_to_underflow(gpu_ctx, oracle):
+    """Inside the integrand the kernels return Bessel values below 2.2e-294 as signed zeros (dev_bessel.h exp_factor,
+    TINY_ZERO) where the oracle keeps the reference's exp(log|f| + e) (bessel.c:44-48): every product of such a value
+    underflows, so the samples must still be the oracle's bits.  Dense gamma sweeps over whole integration ranges, so
+    that hundreds of samples have J_n or J_{n+1} between 1e-323 and 2.2e-294."""
+    rng = np.random.default_rng(77)
+    hit = 0
+    for kind, par, s, th, n in ((0, [2.5, 1., 1e12, 1e10], 40., 0.8, 2000.5), (1, [8.0], 300., 1.1, 5000.),
+                                (0, [3.2, 1., 1e12, 1e10], 5., 0.3, 1500.25), (3, [3.3, 6.0, 0.8, 1e10], 90., 0.6, 3000.)):
+        d, st = oracle_bind.mkdist(oracle, kind, par)
+        assert st == 0
+        nos = n / s
+        root = math.sqrt(nos * nos - math.sin(th) ** 2)
+        gm = (nos - abs(math.cos(th)) * root) / math.sin(th) ** 2
+        gp = (nos + abs(math.cos(th)) * root) / math.sin(th) ** 2
+        g = np.sort(gm + (gp - gm) * rng.random(12000))
+        nn = np.full_like(g, n)
+        for coeff, stokes in ((0, 0), (1, 2)):
+            got = gpu_ctx.gamma_integrand_batch(kind, par, coeff, stokes, s, th, nn, g)
+            ref = np.array([oracle.rimo_gamma_integrand(d, coeff, stokes, s, th, n, float(x)) for x in g])
+            report_mismatch("integrand next to underflow, kind %d" % kind, got, ref, lambda i: (par, s, th, coeff, stokes, n, g[i]))
+        # how many of these samples had a Bessel value in the band the kernels flush (symphony.rs:398-437 kinematics)
+        beta = np.sqrt(1. - 1. / (g * g))
+        cos_xi = (s * g - n) / (s * g * beta * math.cos(th))
+        with np.errstate(invalid="ignore"):
+            z = s * beta * math.sin(th) * g * np.sqrt(1. - cos_xi * cos_xi)
+        z = z[np.isfinite(z)][::8]
+        for order in (n, n + 1.):
+            j = np.abs(np.array([oracle.rimo_bessel_j(order, float(x)) for x in z]))
+            hit += int(((j > 0) & (j < 2.2e-294)).sum())
+    assert hit > 100, hit
+
+
 def test_qag_selftest_bit_exact(gpu_ctx, oracle):
     """Wave-cooperative QAG vs the oracle's GSL-order QAG on +-*/sqrt integrands:
     result, error estimate, status AND subinterval count must agree, including
