@@ -811,7 +811,14 @@ RIM_FN double rim_cbrt_f32core(double x)
 template <int PREC> struct RimMath {
     RIM_FN double exp(double x) { return rim_exp(x); }
     RIM_FN double exp_bounded(double x) { return rim_exp_bounded(x); }
-    RIM_FN double pow(double x, double y) { return rim_pow(x, y); }
+    /* sin_xi^k of the pitch-angle distributions: the base may be 0 (or NaN) and the exponent 0 -- those keep the general
+     * function's special cases; everything else is a positive normal base with a finite exponent, where
+     * rim_pow_normal returns the same bits for half the instructions (tests/test_detmath.py) */
+    RIM_FN double pow(double x, double y)
+    {
+        if (!(x >= 2.2250738585072014e-308) || !rim_isfinite(x) || y == 0.0 || !rim_isfinite(y)) return rim_pow(x, y);
+        return rim_pow_normal(x, y);
+    }
     RIM_FN double pow_normal(double x, double y) { return rim_pow_normal(x, y); }
     RIM_FN double cbrt_normal(double x) { return rim_cbrt_normal(x); }              /* bessel.c:180 pow(x, 1./3.) */
     RIM_FN double powexp_normal(double x, double y, double e) { return rim_powexp_normal(x, y, e); }
