@@ -353,7 +353,7 @@ static double nr_outer_integrand(double pomega, void *ctx)
 {
     hey_state *st = (hey_state *) ctx;
     const double sigma_min = m_sqrt(pomega * pomega + st->sigma0_sq);
-    const double sigma_max = INVERSE_SQRT_3 * m_pow(sigma_min, 1.5);
+    const double sigma_max = INVERSE_SQRT_3 * m_pow15(sigma_min);
     if (sigma_max <= sigma_min)
         return 0.;
     st->fixed = pomega;
@@ -363,7 +363,7 @@ static double nr_outer_integrand(double pomega, void *ctx)
 static double qr_outer_integrand(double sigma, void *ctx)
 {
     hey_state *st = (hey_state *) ctx;
-    const double pomega_max_phys = m_sqrt(THREE_TWO_THIRDS * m_pow(sigma, 4. / 3.) - st->sigma0_sq);
+    const double pomega_max_phys = m_sqrt(THREE_TWO_THIRDS * m_pow43(sigma) - st->sigma0_sq);
     const double pomega_max_qr = m_sqrt(sigma * sigma - st->sigma0_sq);
     const double pomega_max = rust_min(pomega_max_phys, pomega_max_qr);
     st->fixed = sigma;

@@ -19,6 +19,7 @@
 #define m_pow(x, y) pow(x, y)
 #define m_cbrt(x) pow(x, 1. / 3.)
 #define m_pow15(x) pow(x, 1.5)
+#define m_pow43(x) pow(x, 4. / 3.)
 #define m_pow25(x) pow(x, 2.5)
 #define m_lgamma(x) lgamma(x)
 static inline void m_sincos(double x, double *s, double *c) { *s = sin(x); *c = cos(x); }
@@ -33,6 +34,7 @@ static inline double m_cos_phase(double x) { double s, c; rim_sincos(x, &s, &c);
 #define m_pow(x, y) rim_pow(x, y)
 #define m_cbrt(x) rim_cbrt_normal(x) /* the deterministic build's cube root (detmath.h); its one call site has x ~ n >= 30 */
 #define m_pow15(x) rim_pow15(x)
+#define m_pow43(x) rim_pow43(x)
 #define m_pow25(x) rim_pow25(x)
 #define m_lgamma(x) rim_lgamma_pos(x)
 static inline void m_sincos(double x, double *s, double *c) { rim_sincos(x, s, c); }

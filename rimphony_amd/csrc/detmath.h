@@ -577,6 +577,14 @@ RIM_FN void rim_third_powers(double h, double out[4])
 #define RIM_RGAMMA_4_3 1.1198465217221858
 #define RIM_RGAMMA_2_3 0.7384881116216483
 
+/* x^(4/3) (the physical limit of the quasi-resonant pomega range, heyvaerts.rs:270-272 powf(4./3.)) as x cbrt(x) for a
+ * positive normal finite x, through the general power otherwise (0, subnormal, inf, NaN, negative) */
+RIM_FN double rim_pow43(double x)
+{
+    if (x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308) return x * rim_cbrt_normal(x);
+    return rim_pow(x, 4. / 3.);
+}
+
 /* 1 / Gamma(z) for -8.5 < z < 9.5, ~2 ulp (tests/test_detmath.py): z = m + z0 with m the nearest integer, the Taylor
  * series 1 / Gamma(z0) = z0 S(z0) (|z0| <= 1/2, 20 terms), and the recurrence: m >= 1 gives S / ((z0 + 1) .. (z0 + m - 1)),
  * m <= 0 gives z0 S (z0 - 1) .. (z0 + m) -- exactly 0 at the poles.  The J_nu prefactors of the Faraday elements

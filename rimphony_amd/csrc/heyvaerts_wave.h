@@ -153,11 +153,11 @@ __device__ __forceinline__ void hey_eval_pair(const HeyPoint &pt, const DistPara
     bool empty_l = false;
     if (!qr_l) {
         const double sigma_min = rim_sqrt(u_l * u_l + pt.sigma0_sq);
-        const double sigma_max = RIM_INVERSE_SQRT_3 * rim_pow(sigma_min, 1.5);
+        const double sigma_max = RIM_INVERSE_SQRT_3 * rim_pow15(sigma_min);       // sigma_min = sqrt(..) >= 0
         empty_l = sigma_max <= sigma_min;
         lo_l = sigma_min; hi_l = sigma_max;
     } else {
-        const double pomega_max_phys = rim_sqrt(RIM_THREE_TWO_THIRDS * rim_pow(u_l, 4. / 3.) - pt.sigma0_sq);
+        const double pomega_max_phys = rim_sqrt(RIM_THREE_TWO_THIRDS * rim_pow43(u_l) - pt.sigma0_sq);
         const double pomega_max_qr = rim_sqrt(u_l * u_l - pt.sigma0_sq);
         const double pomega_max = rust_min(pomega_max_phys, pomega_max_qr);
         lo_l = -pomega_max; hi_l = pomega_max;
