@@ -174,6 +174,10 @@ typedef struct {
 void rimo_set_tuning(const rimo_tuning *t);
 /* Investigation knob (tools/nan_pattern.py only): count Symphony integrand samples below DBL_MIN as 0.  Default off. */
 void rimo_set_flush_subnormal_samples(int on);
+/* Investigation knob (tools/sample_overlap.py only): record a 64-bit key of (harmonic, gamma) for every Symphony
+ * integrand sample the calling thread evaluates, up to cap keys; NULL switches it off. */
+void rimo_set_sample_log(uint64_t *buf, size_t cap);
+size_t rimo_sample_log_count(void);
 void rimo_get_tuning(rimo_tuning *t);
 
 #ifdef __cplusplus

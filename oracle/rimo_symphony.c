@@ -89,9 +89,21 @@ static double gamma_integrand(sym_state *st, double gamma, double n)
 static int g_flush_subnormal_samples = 0;
 void rimo_set_flush_subnormal_samples(int on) { g_flush_subnormal_samples = on; }
 
+/* investigation knob (tools/sample_overlap.py): log a key of every integrand sample (harmonic, gamma) of this thread */
+static __thread uint64_t *t_sample_log = 0;
+static __thread size_t t_sample_cap = 0, t_sample_count = 0;
+void rimo_set_sample_log(uint64_t *buf, size_t cap) { t_sample_log = buf; t_sample_cap = cap; t_sample_count = 0; }
+size_t rimo_sample_log_count(void) { return t_sample_count; }
+
 static double gamma_integrand_cb(double g, void *ctx)
 {
     sym_state *st = (sym_state *) ctx;
+    if (t_sample_log) {
+        uint64_t a, b;
+        memcpy(&a, &st->cur_n, 8); memcpy(&b, &g, 8);
+        if (t_sample_count < t_sample_cap) t_sample_log[t_sample_count] = a * 0x9E3779B97F4A7C15ull ^ (b + (b << 31) + (b >> 17));
+        t_sample_count++;
+    }
     const double v = gamma_integrand(st, g, st->cur_n);
     if (g_flush_subnormal_samples && m_fabs(v) < RIM_DBL_MIN) return 0.;
     return v;
