@@ -178,7 +178,20 @@ void rimo_set_flush_subnormal_samples(int on);
  * integrand sample the calling thread evaluates, up to cap keys; NULL switches it off. */
 void rimo_set_sample_log(uint64_t *buf, size_t cap);
 size_t rimo_sample_log_count(void);
+/* Investigation knob (tools/lockstep_sim.py only): the raw bit patterns (n, gamma) of every Symphony integrand sample of
+ * the calling thread, in evaluation order, up to cap_pairs pairs; NULL switches it off. */
+void rimo_set_sample_raw_log(uint64_t *buf, size_t cap_pairs);
+size_t rimo_sample_raw_count(void);
 void rimo_get_tuning(rimo_tuning *t);
+/* Investigation knobs (tools/nan_rootcause.py only), thread-local: a log of the quadratures that ended in a GSL error
+ * (level 0 = gamma-integral, symphony.rs:375-380; level 1 = n-chunk, symphony.rs:264-269), and a per-bisection trace of
+ * the next rimo_qag call (14 doubles per iteration: a_i b_i r_i e_i area1 error1 resasc1 area2 error2 resasc2 rt1 rt2
+ * errsum tolerance; row 0 holds the first rule application: a b result0 abserr0 resabs0 resasc0). */
+typedef struct { double n, a, b, result, abserr; int lobe, status, size, level; } rimo_fail_rec;
+void rimo_set_fail_log(rimo_fail_rec *buf, size_t cap);
+size_t rimo_fail_log_count(void);
+void rimo_set_qag_trace(double *buf, size_t cap_rows);
+size_t rimo_qag_trace_rows(void);
 
 #ifdef __cplusplus
 }

@@ -40,13 +40,16 @@ static double rescale_error(double err, const double result_abs, const double re
 }
 
 #ifndef RIMO_LIBM
-/* Sum of 32 values in the order of a 5-level xor butterfly over a 32-lane
- * half-wave: adjacent pairs, then pairs of pairs, ...  (DESIGN.md "GK31
- * reduction order"). */
-static double tree32(double *v)
+/* The deterministic flavour forms QUADPACK's own terms -- w (f1 + f2) per symmetric pair of nodes, the centre alone --
+ * and adds the 16 terms in the order of the wavefront kernel: pair k of the rule (abscissa xgk[k], k = 0..14; slot 15
+ * is the centre) sits on lanes 2k and 2k + 1 of a half-wave, the first butterfly step (xor 1) is the pair sum
+ * f1 + f2, and the remaining four steps (xor 2, 4, 8, 16) add the 16 weighted terms as a balanced binary tree over
+ * the slots: adjacent slots, then pairs of slots, ...  (wave_qag.h wave_gk31; DESIGN.md "GK31 reduction order").
+ * Only the ORDER of these 16 additions differs from qk.c's sequential loops; every term has the reference's bits. */
+static double tree16(double *v)
 {
-    for (int width = 1; width < 32; width <<= 1)
-        for (int i = 0; i < 32; i += 2 * width)
+    for (int width = 1; width < 16; width <<= 1)
+        for (int i = 0; i < 16; i += 2 * width)
             v[i] = v[i] + v[i + width];
     return v[0];
 }
@@ -73,41 +76,53 @@ void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
         result_gauss = f_center * GK_WG[15];
         result_kronrod = f_center * GK_WK[15];
         result_abs = m_fabs(result_kronrod);
-        for (int j = 0; j < 7; j++) {
+        /* -DRIMO_GK_REVERSED (noise-floor control, tools/make_literal_fixtures.py): the same terms added in the
+         * opposite order -- an equally legitimate evaluation of the same rule */
+#ifdef RIMO_GK_REVERSED
+#define GK_LOOP(j, n) for (int j = (n) - 1; j >= 0; j--)
+#else
+#define GK_LOOP(j, n) for (int j = 0; j < (n); j++)
+#endif
+        GK_LOOP(j, 7) {
             const int jtw = 2 * j + 1;
             const double fsum = fv[jtw] + fv[30 - jtw];
             result_gauss += GK_WG[jtw] * fsum;
             result_kronrod += GK_WK[jtw] * fsum;
             result_abs += GK_WK[jtw] * (m_fabs(fv[jtw]) + m_fabs(fv[30 - jtw]));
         }
-        for (int j = 0; j < 8; j++) {
+        GK_LOOP(j, 8) {
             const int jtwm1 = 2 * j;
             result_kronrod += GK_WK[jtwm1] * (fv[jtwm1] + fv[30 - jtwm1]);
             result_abs += GK_WK[jtwm1] * (m_fabs(fv[jtwm1]) + m_fabs(fv[30 - jtwm1]));
         }
         mean = result_kronrod * 0.5;
         result_asc = GK_WK[15] * m_fabs(f_center - mean);
-        for (int j = 0; j < 7; j++) {
+        GK_LOOP(j, 7) {
             const int jtw = 2 * j + 1;
             result_asc += GK_WK[jtw] * (m_fabs(fv[jtw] - mean) + m_fabs(fv[30 - jtw] - mean));
         }
-        for (int j = 0; j < 8; j++) {
+        GK_LOOP(j, 8) {
             const int jtwm1 = 2 * j;
             result_asc += GK_WK[jtwm1] * (m_fabs(fv[jtwm1] - mean) + m_fabs(fv[30 - jtwm1] - mean));
         }
     }
 #else
     {
-        double t[32];
-        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * fv[j];
-        result_kronrod = tree32(t);
-        for (int j = 0; j < 32; j++) t[j] = GK_WG[j] * fv[j];
-        result_gauss = tree32(t);
-        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * m_fabs(fv[j]);
-        result_abs = tree32(t);
+        /* slot k < 15: the pair (node k, node 30 - k) of the ascending table, weight GK_WK[k] = GK_WK[30 - k]; slot 15: centre */
+        double t[16];
+        for (int k = 0; k < 15; k++) t[k] = GK_WK[k] * (fv[k] + fv[30 - k]);
+        t[15] = GK_WK[15] * (fv[15] + 0.0);
+        result_kronrod = tree16(t);
+        for (int k = 0; k < 15; k++) t[k] = GK_WG[k] * (fv[k] + fv[30 - k]);
+        t[15] = GK_WG[15] * (fv[15] + 0.0);
+        result_gauss = tree16(t);
+        for (int k = 0; k < 15; k++) t[k] = GK_WK[k] * (m_fabs(fv[k]) + m_fabs(fv[30 - k]));
+        t[15] = GK_WK[15] * (m_fabs(fv[15]) + 0.0);
+        result_abs = tree16(t);
         mean = result_kronrod * 0.5;
-        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * m_fabs(fv[j] - mean);
-        result_asc = tree32(t);
+        for (int k = 0; k < 15; k++) t[k] = GK_WK[k] * (m_fabs(fv[k] - mean) + m_fabs(fv[30 - k] - mean));
+        t[15] = GK_WK[15] * (m_fabs(fv[15] - mean) + 0.0);     /* the padding lane holds 0, not |0 - mean| */
+        result_asc = tree16(t);
     }
 #endif
 
@@ -263,6 +278,12 @@ static int subinterval_too_small(double a1, double a2, double b2)
     return m_fabs(a1) <= tmp && m_fabs(b2) <= tmp;
 }
 
+/* investigation knob (rimo.h): per-bisection trace of the calling thread's next rimo_qag call */
+static __thread double *t_trace = 0;
+static __thread size_t t_trace_cap = 0, t_trace_rows = 0;
+void rimo_set_qag_trace(double *buf, size_t cap_rows) { t_trace = buf; t_trace_cap = cap_rows; t_trace_rows = 0; }
+size_t rimo_qag_trace_rows(void) { return t_trace_rows; }
+
 /* qag.c */
 int rimo_qag(rimo_fn f, void *ctx, double a, double b, double epsabs, double epsrel,
              size_t limit, rimo_workspace *w, double *result, double *abserr, uint64_t *gk_evals)
@@ -284,9 +305,17 @@ int rimo_qag(rimo_fn f, void *ctx, double a, double b, double epsabs, double eps
     if (epsabs <= 0 && (epsrel < 50 * RIM_DBL_EPSILON || epsrel < 0.5e-28))
         return RIMO_EBADTOL;
 
+    double *const trace = t_trace;          /* armed for this call only (nested calls run untraced) */
+    t_trace = 0;
     rimo_qk31(f, ctx, a, b, &result0, &abserr0, &resabs0, &resasc0);
     nev++;
     ws_set_initial_result(w, result0, abserr0);
+    if (trace && t_trace_cap) {
+        double *r = trace;
+        r[0] = a; r[1] = b; r[2] = result0; r[3] = abserr0; r[4] = resabs0; r[5] = resasc0;
+        for (int k = 6; k < 14; k++) r[k] = 0.;
+        t_trace_rows = 1;
+    }
 
     tolerance = rim_max(epsabs, epsrel * m_fabs(result0));
     round_off = 50 * RIM_DBL_EPSILON * resabs0;
@@ -356,6 +385,13 @@ int rimo_qag(rimo_fn f, void *ctx, double a, double b, double epsabs, double eps
                 error_type = 2; /* round off error */
             if (subinterval_too_small(a1, a2, b2))
                 error_type = 3;
+        }
+
+        if (trace && t_trace_rows < t_trace_cap) {
+            double *r = trace + 14 * t_trace_rows++;
+            r[0] = a_i; r[1] = b_i; r[2] = r_i; r[3] = e_i; r[4] = area1; r[5] = error1; r[6] = resasc1;
+            r[7] = area2; r[8] = error2; r[9] = resasc2; r[10] = roundoff_type1; r[11] = roundoff_type2;
+            r[12] = errsum; r[13] = tolerance;
         }
 
         ws_update(w, a1, b1, area1, error1, a2, b2, area2, error2);
@@ -454,7 +490,11 @@ double rimo_hyperg_2F1_at_1(double a, double b, double c)
 
 const char *rimo_build_flavour(void)
 {
-#ifdef RIMO_LIBM
+#if defined(RIMO_LIBM) && defined(RIMO_GK_REVERSED)
+    return "libm+gsl-order-reversed";
+#elif defined(RIMO_LIBM) && defined(__FP_FAST_FMA) && defined(RIMO_CONTRACT)
+    return "libm+gsl-order+contracted";
+#elif defined(RIMO_LIBM)
     return "libm+gsl-order";
 #else
     return "detmath+tree-order";

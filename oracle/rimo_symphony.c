@@ -95,9 +95,37 @@ static __thread size_t t_sample_cap = 0, t_sample_count = 0;
 void rimo_set_sample_log(uint64_t *buf, size_t cap) { t_sample_log = buf; t_sample_cap = cap; t_sample_count = 0; }
 size_t rimo_sample_log_count(void) { return t_sample_count; }
 
+/* investigation knob (rimo.h): log of the quadratures of this thread that ended in a GSL error */
+static __thread rimo_fail_rec *t_fail_log = 0;
+static __thread size_t t_fail_cap = 0, t_fail_count = 0;
+void rimo_set_fail_log(rimo_fail_rec *buf, size_t cap) { t_fail_log = buf; t_fail_cap = cap; t_fail_count = 0; }
+size_t rimo_fail_log_count(void) { return t_fail_count; }
+static void fail_log(double n, double a, double b, double result, double abserr, int lobe, int status, size_t size, int level)
+{
+    if (t_fail_log && t_fail_count < t_fail_cap) {
+        rimo_fail_rec *r = t_fail_log + t_fail_count;
+        r->n = n; r->a = a; r->b = b; r->result = result; r->abserr = abserr;
+        r->lobe = lobe; r->status = status; r->size = (int) size; r->level = level;
+    }
+    if (t_fail_log) t_fail_count++;
+}
+
+/* investigation knob (tools/lockstep_sim.py): the raw (n, gamma) bit patterns of every sample, in evaluation order */
+static __thread uint64_t *t_sample_raw = 0;
+static __thread size_t t_raw_cap = 0, t_raw_count = 0;
+void rimo_set_sample_raw_log(uint64_t *buf, size_t cap_pairs) { t_sample_raw = buf; t_raw_cap = cap_pairs; t_raw_count = 0; }
+size_t rimo_sample_raw_count(void) { return t_raw_count; }
+
 static double gamma_integrand_cb(double g, void *ctx)
 {
     sym_state *st = (sym_state *) ctx;
+    if (t_sample_raw) {
+        if (t_raw_count < t_raw_cap) {
+            memcpy(&t_sample_raw[2 * t_raw_count], &st->cur_n, 8);
+            memcpy(&t_sample_raw[2 * t_raw_count + 1], &g, 8);
+        }
+        t_raw_count++;
+    }
     if (t_sample_log) {
         uint64_t a, b;
         memcpy(&a, &st->cur_n, 8); memcpy(&b, &g, 8);
@@ -145,6 +173,7 @@ static double gamma_integral(sym_state *st, double n)
         st->c->inner_qag_calls++;
         if (st->gamma_ws->size > st->c->max_inner_size) st->c->max_inner_size = st->gamma_ws->size;
     }
+    if (status) fail_log(n, gamma0, gamma1, result, abserr, st->negative_lobe, status, st->gamma_ws->size, 0);
     return status ? RIM_NAN : result;
 }
 
@@ -192,7 +221,11 @@ static double n_integration(sym_state *st, double n_start, int *failed)
                 st->c->outer_qag_calls++;
                 if (n_ws->size > st->c->max_outer_size) st->c->max_outer_size = n_ws->size;
             }
-            if (status) { *failed = 1; break; }
+            if (status) {
+                fail_log(n_start, n_start, n_start + delta_n, contrib, abserr, st->negative_lobe, status, n_ws->size, 1);
+                *failed = 1;
+                break;
+            }
         }
 
         ans += contrib;

@@ -132,5 +132,6 @@ def check(rc, what):
     if rc != 0:
         lib = load()
         msg = lib.rimphony_strerror(rc).decode()
-        detail = lib.rimphony_last_error().decode()
+        # the thread's last HIP failure only describes this call when this call failed in HIP (RIMPHONY_EHIP = -2)
+        detail = lib.rimphony_last_error().decode() if rc == -2 else ""
         raise RimphonyError("%s failed: %s (code %d)%s" % (what, msg, rc, " -- " + detail if detail else ""))

@@ -220,11 +220,18 @@ RIM_DEV void sym_bessel_pair(const SymOrder &so, double z, double &jn, double &d
     djn = n * jn / z - jnp1;
 }
 
-template <int KIND, int PREC = 0>
-RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const SymOrder &so, double gamma)
+// gamma_integrand (symphony.rs:398-479) in three pieces, so that the coefficients of one parameter point can share
+// the part that depends on (s, theta, n, gamma) only -- the kinematics and the Bessel pair, symphony.rs:406-442 -- and
+// differ in the polarisation term (:444-448) and the distribution term (:455-463): symphony_group.h.
+struct GiShared {
+    double gamma, beta, cos_xi;
+    double mj, njp;             // M J_n(z), N J'_n(z)
+};
+
+template <int PREC = 0>
+RIM_DEV GiShared gamma_integrand_shared(double s, double cos_th, double sin_th, const SymOrder &so, double gamma)
 {
-    const double s = pt.s, n = so.n;
-    const double cos_th = pt.cos_th, sin_th = pt.sin_th;
+    const double n = so.n;
 
     const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
     // (numerators that can be exactly 0 give the IEEE signed zero through the bare sequence too)
@@ -253,35 +260,49 @@ RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const Sy
     RIM_PROF_T(t_bes);
     sym_bessel_pair<PREC>(so, z, jn, djn);
     RIM_PROF_ADD(2, t_bes);
-    RIM_PROF_T(t_f);
-    const double mj = m * jn;
-    const double njp = big_n * djn;
+    GiShared sh;
+    sh.gamma = gamma; sh.beta = beta; sh.cos_xi = cos_xi;
+    sh.mj = m * jn;
+    sh.njp = big_n * djn;
+    return sh;
+}
 
-    double pol_term;
-    if (pt.stokes == STOKES_I) pol_term = mj * mj + njp * njp;
-    else if (pt.stokes == STOKES_Q) pol_term = mj * mj - njp * njp;
-    else pol_term = 2. * mj * njp;
+RIM_DEV double gamma_integrand_pol_term(int stokes, double mj, double njp)
+{
+    if (stokes == STOKES_I) return mj * mj + njp * njp;
+    if (stokes == STOKES_Q) return mj * mj - njp * njp;
+    return 2. * mj * njp;
+}
 
-    double f_term;
-    if (pt.coeff == COEFF_EMISSION) {
+template <int KIND, int PREC = 0>
+RIM_DEV double gamma_integrand_f_term(int coeff, const DistParams &d, double cos_th, const GiShared &sh)
+{
+    const double gamma = sh.gamma, beta = sh.beta, cos_xi = sh.cos_xi;
+    if (coeff == COEFF_EMISSION) {
         RIM_HIT(24);
-        f_term = calc_f<KIND, PREC>(d, gamma, cos_xi);
-    } else {
-        double dfdg, dfdcx;
-        RIM_HIT(25);
-        calc_f_derivatives<KIND, PREC>(d, gamma, cos_xi, dfdg, dfdcx);
-        if (KIND == DIST_POWER_LAW || KIND == DIST_THERMAL_JUETTNER) {
-            // dfdcx is the constant +0 (isotropic distributions): dfdcx_factor * dfdcx is a zero with the sign of the
-            // factor (a NaN only where the sample is a NaN through cos_xi anyway), and for gamma > 0 the factor
-            // (beta cos_th - cos_xi) / (gamma - 1 / gamma) has the sign of (beta cos_th - cos_xi) (gamma - 1): the
-            // same bits -- signed zeros of f_term included -- without the two divisions.
-            f_term = dfdg + ((beta * cos_th - cos_xi) * dfdcx) * (gamma - 1.);
-        } else {
-            const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
-            f_term = dfdg + dfdcx_factor * dfdcx;
-        }
+        return calc_f<KIND, PREC>(d, gamma, cos_xi);
     }
+    double dfdg, dfdcx;
+    RIM_HIT(25);
+    calc_f_derivatives<KIND, PREC>(d, gamma, cos_xi, dfdg, dfdcx);
+    if (KIND == DIST_POWER_LAW || KIND == DIST_THERMAL_JUETTNER) {
+        // dfdcx is the constant +0 (isotropic distributions): dfdcx_factor * dfdcx is a zero with the sign of the
+        // factor (a NaN only where the sample is a NaN through cos_xi anyway), and for gamma > 0 the factor
+        // (beta cos_th - cos_xi) / (gamma - 1 / gamma) has the sign of (beta cos_th - cos_xi) (gamma - 1): the
+        // same bits -- signed zeros of f_term included -- without the two divisions.
+        return dfdg + ((beta * cos_th - cos_xi) * dfdcx) * (gamma - 1.);
+    }
+    const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
+    return dfdg + dfdcx_factor * dfdcx;
+}
 
+template <int KIND, int PREC = 0>
+RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const SymOrder &so, double gamma)
+{
+    const GiShared sh = gamma_integrand_shared<PREC>(pt.s, pt.cos_th, pt.sin_th, so, gamma);
+    RIM_PROF_T(t_f);
+    const double pol_term = gamma_integrand_pol_term(pt.stokes, sh.mj, sh.njp);
+    const double f_term = gamma_integrand_f_term<KIND, PREC>(pt.coeff, d, pt.cos_th, sh);
     RIM_PROF_ADD(6, t_f);
     return gamma * gamma * pol_term * f_term;
 }

@@ -1,0 +1,43 @@
+// group_launch.h -- what rimphony_hip.hip (host side) and rimphony_group.hip (the kernel) agree on.
+#ifndef RIM_GROUP_LAUNCH_H
+#define RIM_GROUP_LAUNCH_H
+
+#include "symphony_group.h"
+#include "coop_common.h"
+
+// waves per SIMD the register allocator must leave room for (4 x 16 waves per CU: 10 KB of LDS each)
+#ifndef RIM_GROUP_WAVES
+#define RIM_GROUP_WAVES 4
+#endif
+// entries of one published round: up to 62 lanes x RIM_GROUP classes
+#define RIM_GROUP_ENTRIES 248
+
+// Board slot of the group kernel (cooperative tail; protocol: coop_common.h).  An entry = one merged request
+// (n, lobe, member mask); its result = per member a value, status bits and the integrand samples the member's
+// quadrature consumed.
+struct GroupSlot {
+    unsigned long long claim;       // (seq << 32) | (count << 8) | next
+    unsigned long long point;
+    unsigned done;
+    unsigned slots;                 // the group's members (symphony_group.h: group_slot)
+    unsigned long long req_n[256];  // bit patterns of doubles: every access is an agent-scope atomic
+    int req_tag[256];               // lobe | member mask << 1
+    unsigned long long res[256 * RIM_GROUP];
+    int res_status[256];            // 8 status bits per member
+    unsigned res_samples[256 * RIM_GROUP];
+};
+
+struct GroupArgs {
+    SymArgs base;                   // slot[] / nslots / board / spill of the base are not used by the group kernel
+    int ngroups;
+    unsigned gslots[2];             // members of group 0 and 1, 4 bits per member (output slots 0..5)
+    int gnmem[2];
+    GroupSlot *gboard;              // [gridDim.x]
+    double *gspill;                 // [gridDim.x][SPILL_GROUP_DOUBLES_PER_WAVE]
+    int coop;                       // cooperative tail on
+};
+
+const void *rim_group_kernel(int kind);
+int rim_group_launch(int kind, unsigned grid, hipStream_t st, const GroupArgs &ga);
+
+#endif

@@ -140,6 +140,8 @@ extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const
 {
     if (!c || (count && (!d_n_lo || !d_n_hi || !d_out))) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
     PointArgs pa;
     int rc = rim_point_setup(c, kind, params, coeff, stokes, negative_lobe, s, theta, st, pa);
     if (rc) return rc;
@@ -165,6 +167,8 @@ extern "C" int rimphony_gamma_contribution_batch_device(rimphony_ctx *c, int kin
 {
     if (!c || (count && (!d_gamma || !d_out))) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
     PointArgs pa;
     int rc = rim_point_setup(c, kind, params, coeff, stokes, 0, s, theta, st, pa);
     if (rc) return rc;
@@ -212,6 +216,8 @@ extern "C" int rimphony_calc_f_batch_device(rimphony_ctx *c, int kind, const dou
 {
     if (!c || (count && (!d_gamma || !d_cos_xi))) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
     PointArgs pa;
     // coefficient / stokes / s / theta play no part in f; any valid values satisfy the argument checks
     int rc = rim_point_setup(c, kind, params, 0, 0, 0, 1., 1., st, pa);
@@ -325,6 +331,8 @@ extern "C" int rimphony_hey_element_batch_device(rimphony_ctx *c, int kind, cons
 {
     if (!c || (count && (!d_fixed || !d_v || !d_out)) || (stokes != RIMPHONY_STOKES_Q && stokes != RIMPHONY_STOKES_V)) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
     PointArgs pa;
     int rc = rim_point_setup(c, kind, params, 0, stokes, 0, s, theta, st, pa);
     if (rc) return rc;
@@ -346,6 +354,8 @@ extern "C" int rimphony_hey_outer_batch_device(rimphony_ctx *c, int kind, const 
 {
     if (!c || (count && (!d_u || !d_out)) || (stokes != RIMPHONY_STOKES_Q && stokes != RIMPHONY_STOKES_V)) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
     PointArgs pa;
     int rc = rim_point_setup(c, kind, params, 0, stokes, 0, s, theta, st, pa);
     if (rc) return rc;

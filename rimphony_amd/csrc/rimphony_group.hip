@@ -1,0 +1,512 @@
+// rimphony_group.hip -- group_kernel<KIND>: the Symphony coefficients of a parameter point in lock-step (gfx950 only).
+//
+// Task = (point, group); group IQ = the selected ones of {j_I, alpha_I, j_Q, alpha_Q}, group V = those of {j_V, alpha_V}
+// (symphony_group.h says why and what is shared).  The kernel has the shape of coop_kernel (rimphony_hip.hip): a
+// persistent grid of single-wave workgroups pulling tasks from one atomic counter, and a cooperative tail -- once the
+// queue is empty, a wave that still owns a task publishes the merged ENTRIES (n, lobe, member mask) of each round on
+// its board slot, idle waves claim single entries, run the members' gamma-integrals in lock-step and hand back one
+// value, status and sample count per member.  An entry is a pure function of (point, group, n, lobe, mask), so who
+// evaluates it changes no bit; the members' sample counts travel with the values and are booked by the owner when
+// it consumes the batch, so the per-coefficient work counters do not depend on who helped either.
+//
+// A translation unit of its own: hipcc's code generation for a kernel of this size depends on what else is in the
+// unit (rimphony_internal.h).
+#include <hip/hip_runtime.h>
+#include "../../include/rimphony_hip.h"
+#include "symphony_group.h"
+#include "rimphony_internal.h"
+#include "coop_common.h"
+#include "group_launch.h"
+
+using namespace rim;
+
+// claim the next unevaluated entry of batch `seq` on a group slot; -1 if there is none (or the batch is over)
+__device__ __forceinline__ int group_claim(GroupSlot *slot, unsigned seq, int lane)
+{
+    int k = -1;
+    if (lane == 0) {
+        for (int tries = 0; tries < 64; tries++) {
+            const unsigned long long c = __hip_atomic_load(&slot->claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned) (c >> 32) != seq || !claim_open(c)) break;
+            unsigned long long expect = c;
+            if (__hip_atomic_compare_exchange_strong(&slot->claim, &expect, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) { k = (int) (c & 0xff); break; }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(k);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga)
+{
+    const SymArgs &a = ga.base;
+    __shared__ double s_tab[96];
+    __shared__ double s_ginner[RIM_GROUP * RIM_ISTORE_DOUBLES(CAP_GINNER)];
+    __shared__ TaskState s_park[RIM_GROUP];
+    __shared__ GroupPark s_gp;
+    const GKLane g = gk_lane_init(s_tab);
+    const int lane = g.lane;
+    double *const inner_spill = ga.gspill + (size_t) blockIdx.x * SPILL_GROUP_DOUBLES_PER_WAVE;
+    double *const outer_spill = inner_spill + RIM_GROUP * RIM_ISTORE_DOUBLES(SPILL_GINNER);
+    if (threadIdx.x == 0) {
+        s_gp.ctr = WaveCounters{0, 0, 0};
+        s_gp.member_passes = 0; s_gp.stash_filed = 0; s_gp.stash_used = 0;
+        s_gp.hb = nullptr;
+    }
+
+    GroupSlot *const my = ga.gboard + blockIdx.x;
+    unsigned *const flag_exhausted = a.board_flags + BOARD_FLAG_EXHAUSTED;
+    unsigned *const flag_active = a.board_flags + BOARD_FLAG_ACTIVE;
+    unsigned *const flag_idle = a.board_flags + BOARD_FLAG_IDLE;
+    unsigned *const hints = a.board_flags + BOARD_HINTS;
+    const bool coop = ga.gboard != nullptr && a.board_flags != nullptr && ga.coop != 0;
+    const unsigned nboard = gridDim.x;
+    unsigned seq = 0;                      // sequence number of this wave's published batches
+    bool counted_idle = false;
+    int backoff = 1;
+    unsigned long long idle_since = 0;
+    unsigned n_polls = 0;
+
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) ga.ngroups;
+    SymPoint pt0;                          // context of the entries being evaluated (own task or a helped one)
+    DistParams dist;
+    unsigned slots = 0;
+    pt0.s = 0.; pt0.cos_th = 0.; pt0.sin_th = 0.; pt0.coeff = 0; pt0.stokes = 0;
+    unsigned long long *const queue = a.queue;
+    size_t own_i = 0;
+    unsigned own_slots = 0;
+    int own_nmem = 0, own_group = 0;
+    unsigned alive = 0;
+    bool have_task = false, helper = false, board_dead = false;
+    unsigned last_hint = 0;
+
+    __builtin_amdgcn_s_setprio(3);
+    for (;;) {
+        // per-lane requests of the round (owner only)
+        double rq0 = 0., rq1 = 0., rq2 = 0., rq3 = 0.;
+        int rl0 = 0, rl1 = 0, rl2 = 0, rl3 = 0;
+        unsigned act = 0, posted = 0;
+        int nq0 = 0, nq1 = 0, nq2 = 0, nq3 = 0;
+        int ph0 = PH_DONE, ph1 = PH_DONE, ph2 = PH_DONE, ph3 = PH_DONE;
+        GroupClasses gc;
+        gc.reps = 0; gc.cmask = 0;
+        int ebase = 0, ecount = 0;             // this lane's first entry ordinal, number of entries of the round
+        GroupSlot *src = my;
+        unsigned src_seq = 0;
+        bool shared = false;
+
+        if (!helper) {
+            // ---------- owner: next round of the current task (fetching a task first if needed) ----------
+            if (!have_task) {
+                const unsigned long long t = wave_next_task(queue, lane);
+                if (t >= ntasks) {
+                    helper = true;
+                    if (lane == 0) {
+                        __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (coop) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    counted_idle = true;
+                    __builtin_amdgcn_s_setprio(0);
+                    if (!coop) break;
+                    continue;
+                }
+                const size_t seqidx = (size_t) (t / (unsigned) ga.ngroups);
+                own_i = a.perm ? (size_t) a.perm[seqidx] : seqidx;
+                own_group = (int) (t % (unsigned) ga.ngroups);
+                own_slots = own_group ? ga.gslots[1] : ga.gslots[0];
+                own_nmem = own_group ? ga.gnmem[1] : ga.gnmem[0];
+                double norm;
+                load_context<KIND>(a, own_i, group_slot(own_slots, 0), pt0, dist, norm);
+                slots = own_slots;
+                __syncthreads();
+                if (!(norm == norm)) {
+                    if (lane == 0) {
+                        for (int m = 0; m < own_nmem; m++) {
+                            const int sl = group_slot(own_slots, m);
+                            a.out[own_i * 8 + sl] = RIM_NAN;
+                            if (a.status) a.status[own_i * 8 + sl] = ST_NORM_FAIL | ST_NONFINITE;
+                        }
+                    }
+                    continue;
+                }
+                alive = 0;
+                for (int m = 0; m < own_nmem; m++) {
+                    SymPoint pt = pt0;
+                    pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
+                    TaskState T0;
+                    sym_begin(pt, T0);
+                    __syncthreads();
+                    if (lane == 0) s_park[m] = T0;
+                    if (T0.phase != PH_DONE) alive |= 1u << m;
+                }
+                __syncthreads();
+                have_task = true;
+            }
+            if (!alive) {
+                // every member has finished: results (symphony.rs:144-183)
+                for (int m = 0; m < own_nmem; m++) {
+                    SymPoint pt = pt0;
+                    pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
+                    TaskState T = s_park[m];
+                    task_uniformize(T);
+                    int st = 0;
+                    const double val = sym_result(pt, T, st);
+                    if (lane == 0) {
+                        const int sl = group_slot(own_slots, m);
+                        a.out[own_i * 8 + sl] = val;
+                        if (a.status) a.status[own_i * 8 + sl] = st;
+                    }
+                }
+                __syncthreads();
+                have_task = false;
+                continue;
+            }
+            // the members that are furthest behind post their batches (symphony_group.h: group_turn)
+            const unsigned turn = group_turn(s_park, alive);
+            for (unsigned rem = turn; rem; rem &= rem - 1) {
+                const int m = __builtin_ctz(rem);
+                SymPoint pt = pt0;
+                pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
+                const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+                TaskState T = s_park[m];
+                task_uniformize(T);
+                SymBatch B;
+                const bool ok = sym_post(pt, g, outer, T, B);
+                __syncthreads();
+                if (lane == 0) s_park[m] = T;
+                if (!ok) { alive &= ~(1u << m); continue; }
+                posted |= 1u << m;
+                put4(m, B.req_n, rq0, rq1, rq2, rq3);
+                put4(m, B.req_lobe, rl0, rl1, rl2, rl3);
+                put4(m, B.n_req, nq0, nq1, nq2, nq3);
+                put4(m, B.phase, ph0, ph1, ph2, ph3);
+                if (B.req_active) act |= 1u << m;
+            }
+            __syncthreads();
+            if (!posted) continue;
+            gc = group_classify(act, rq0, rq1, rq2, rq3, rl0, rl1, rl2, rl3);
+            {
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int j = 0; j < RIM_GROUP; j++) {
+                    const unsigned long long bj = wv_ballot(((gc.reps >> j) & 1u) != 0);
+                    ebase += __builtin_popcountll(bj & below);
+                    ecount += __builtin_popcountll(bj);
+                }
+            }
+
+            // publish the round when some wave is idle
+            unsigned idle = 0, actw = 1;
+            if (lane == 0 && coop) {
+                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    idle = __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    actw = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
+            actw = (unsigned) __builtin_amdgcn_readfirstlane((int) actw);
+            shared = idle != 0 && ecount >= 2 && ecount <= RIM_GROUP_ENTRIES && !board_dead;
+            if (shared) {
+                seq += 1;
+                src_seq = seq;
+#pragma unroll
+                for (int m = 0; m < RIM_GROUP; m++) {
+                    if ((gc.reps >> m) & 1u) {
+                        const int e = ebase + __builtin_popcount(gc.reps & ((1u << m) - 1u));
+                        bput(&my->req_n[e], rim_bits(sel4(m, rq0, rq1, rq2, rq3)));
+                        bput(&my->req_tag[e], sel4(m, rl0, rl1, rl2, rl3) | (int) (((gc.cmask >> (4 * m)) & 15u) << 1));
+                    }
+                }
+                if (lane == 0) {
+                    bput(&my->point, (unsigned long long) own_i);
+                    bput(&my->slots, own_slots);
+                    bput(&my->done, 0u);
+                }
+                drain_vmem();
+                __syncthreads();
+                if (lane == 0)
+                    __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) ecount << 8),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                drain_vmem();          // the claim word is out before anybody can see the hint
+                __syncthreads();
+                {
+                    const unsigned span = hint_span(actw);
+                    const unsigned channel = ((unsigned) blockIdx.x + seq) & (span - 1u);
+                    if (((unsigned) lane & (span - 1u)) == channel)
+                        __hip_atomic_store(&hints[(unsigned) lane * BOARD_HINT_STRIDE], (seq << 16) | ((unsigned) blockIdx.x + 1u),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else {
+            // ---------- helper: find a published round through this wave's hint line ----------
+            unsigned h = 0, actw = 1;
+            int leave = 0;
+            unsigned long long c = 0;
+            if (lane == 0) {
+                if ((n_polls & 15u) == 0) {
+                    actw = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // more idle waves than the remaining owners can feed only add polling traffic: the surplus leaves
+                    const unsigned keep = actw * 64u + 32u;
+                    if (counted_idle && actw != 0 &&
+                        __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > keep) {
+                        const unsigned before = __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (before > keep) leave = 1;
+                        else __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (!leave)
+                    h = __hip_atomic_load(&hints[((unsigned) blockIdx.x & 63u) * BOARD_HINT_STRIDE], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned hs = h & 0xffffu;
+                if (h != last_hint && hs != 0 && hs <= nboard) {
+                    c = __hip_atomic_load(&ga.gboard[hs - 1].claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!claim_open(c)) { last_hint = h; h = 0; }      // nothing left of that round: wait for a new hint
+                } else {
+                    h = 0;
+                }
+            }
+            h = (unsigned) __builtin_amdgcn_readfirstlane((int) h);
+            actw = (unsigned) __builtin_amdgcn_readfirstlane((int) actw);
+            if (__builtin_amdgcn_readfirstlane(leave)) break;
+            n_polls += 1;
+            if (h == 0) {
+                if (actw == 0) break;       // every task is finished
+                // a wave that has seen nothing to do for 2 s leaves: it holds no claim, so leaving is always safe, and
+                // it bounds every wait of this kernel
+                const unsigned long long now = wall_clock64();
+                if (idle_since == 0) idle_since = now;
+                else if (now - idle_since > a.idle_ticks) {
+                    if (counted_idle && lane == 0)
+                        __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
+                if (backoff < 16) backoff *= 2;
+                continue;
+            }
+            h &= 0xffffu;
+            const unsigned long long cw = bcast_u64(c);
+            src = ga.gboard + (h - 1u);
+            src_seq = (unsigned) (cw >> 32);
+            shared = true;
+        }
+
+        // ---------- evaluate entries of `src` (the integrand lives here, once) ----------
+        double gv0 = 0., gv1 = 0., gv2 = 0., gv3 = 0.;
+        int bs0 = 0, bs1 = 0, bs2 = 0, bs3 = 0;
+        bool ctx_loaded = !helper;
+        int got = 0;
+        size_t work_i = own_i;
+        bool redo;
+        do {
+        redo = false;
+        unsigned long long lanes = helper ? 0ull : wv_ballot(gc.reps != 0);
+        int cur_k = -1;
+        unsigned cur_bits = 0;
+        for (;;) {
+            double n0 = 0., n1 = 0.;
+            int lb0 = 0, lb1 = 0, ek0 = -1, ek1 = -1, eidx = -1;
+            unsigned mk0 = 0, mk1 = 0;
+            if (shared) {
+                eidx = group_claim(src, src_seq, lane);      // ordinal of the entry within the round
+                if (eidx < 0) break;
+                if (helper && !ctx_loaded) {
+                    double norm;
+                    const size_t hi = (size_t) bcast_u64(bget(&src->point));
+                    slots = (unsigned) __builtin_amdgcn_readfirstlane((int) bget(&src->slots));
+                    load_context<KIND>(a, hi, group_slot(slots, 0), pt0, dist, norm);
+                    work_i = hi;
+                    ctx_loaded = true;
+                    if (counted_idle) {
+                        if (lane == 0) __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        counted_idle = false;
+                    }
+                    backoff = 1;
+                    idle_since = 0;
+                }
+                n0 = uni(rim_frombits(bget(&src->req_n[eidx])));
+                const int tag = __builtin_amdgcn_readfirstlane(bget(&src->req_tag[eidx]));
+                lb0 = tag & 1;
+                mk0 = ((unsigned) tag >> 1) & 15u;
+                n1 = n0; lb1 = lb0;
+            } else {
+                // the wave's own round: two entries at a time share their first rule application
+                for (int e = 0; e < 2; e++) {
+                    if (cur_bits == 0) {
+                        if (!lanes) break;
+                        cur_k = __builtin_ffsll((long long) lanes) - 1;
+                        lanes &= lanes - 1;
+                        cur_bits = (unsigned) wv_readlane((int) gc.reps, cur_k);
+                    }
+                    const int em = __builtin_ctz(cur_bits);
+                    cur_bits &= cur_bits - 1;
+                    const double nn = readlane_d(sel4(em, rq0, rq1, rq2, rq3), cur_k);
+                    const int ll = wv_readlane(sel4(em, rl0, rl1, rl2, rl3), cur_k);
+                    const unsigned mm = ((unsigned) wv_readlane((int) gc.cmask, cur_k) >> (4 * em)) & 15u;
+                    if (e == 0) { ek0 = cur_k; n0 = nn; lb0 = ll; mk0 = mm; n1 = nn; lb1 = ll; }
+                    else { ek1 = cur_k; n1 = nn; lb1 = ll; mk1 = mm; }
+                }
+                if (ek0 < 0) break;
+            }
+            got += 1;
+            sym_eval_group<KIND>(pt0, dist, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
+            if (shared) {
+                // hand the members' values, status bits and sample counts back through the board
+                if (lane == 0) {
+                    int stw = 0;
+                    for (unsigned rem = mk0; rem; rem &= rem - 1) {
+                        const int m = __builtin_ctz(rem);
+                        int st = 0;
+                        const double v = group_entry_value(&s_gp, m, 0, st);
+                        bput(&src->res[eidx * RIM_GROUP + m], rim_bits(v));
+                        bput(&src->res_samples[eidx * RIM_GROUP + m], s_gp.mem[m].samples);
+                        stw |= (st & 0xff) << (8 * m);
+                    }
+                    bput(&src->res_status[eidx], stw);
+                    drain_vmem();
+                    __hip_atomic_fetch_add(&src->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                for (int e = 0; e < 2; e++) {
+                    const unsigned mk = e ? mk1 : mk0;
+                    const int ek = e ? ek1 : ek0;
+                    for (unsigned rem = mk; rem; rem &= rem - 1) {
+                        const int m = __builtin_ctz(rem);
+                        int st = 0;
+                        const double v = group_entry_value(&s_gp, m, e, st);
+                        put4(m, sel4(m, bs0, bs1, bs2, bs3) | st, bs0, bs1, bs2, bs3);
+                        if (lane == ek) put4(m, v, gv0, gv1, gv2, gv3);
+                    }
+                }
+                if (a.work && lane == 0) {
+                    // (both entries of a pair are booked in mem[m].samples of their members)
+                    for (unsigned rem = mk0 | mk1; rem; rem &= rem - 1) {
+                        const int m = __builtin_ctz(rem);
+                        atomicAdd(a.work + work_i * 8 + (size_t) group_slot(slots, m), (unsigned long long) s_gp.mem[m].samples);
+                    }
+                }
+            }
+        }
+        if (helper) break;
+
+        // ---------- owner: collect a shared round ----------
+        if (shared) {
+            const unsigned want = (unsigned) ecount;
+            bool complete = false;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                unsigned dn = 0;
+                if (lane == 0) dn = __hip_atomic_load(&my->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dn = (unsigned) __builtin_amdgcn_readfirstlane((int) dn);
+                if (dn >= want) { complete = true; break; }
+                if (wall_clock64() - t0 > a.owner_ticks) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (lane == 0)
+                __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (complete) {
+                // lane k reads the results of its own entries: member mm's value comes from the entry of its class
+                int st_l0 = 0, st_l1 = 0, st_l2 = 0, st_l3 = 0;
+#pragma unroll
+                for (int mm = 0; mm < RIM_GROUP; mm++) {
+                    if ((act >> mm) & 1u) {
+                        int r = 0;           // the member that represents mm's class on this lane
+#pragma unroll
+                        for (int q = 0; q < RIM_GROUP; q++)
+                            if ((gc.cmask >> (4 * q)) & (1u << mm)) r = q;
+                        const int e = ebase + __builtin_popcount(gc.reps & ((1u << r) - 1u));
+                        const double v = rim_frombits(bget(&my->res[e * RIM_GROUP + mm]));
+                        const int stl = (bget(&my->res_status[e]) >> (8 * mm)) & 0xff;
+                        put4(mm, v, gv0, gv1, gv2, gv3);
+                        put4(mm, stl, st_l0, st_l1, st_l2, st_l3);
+                        if (a.work) atomicAdd(a.work + own_i * 8 + (size_t) group_slot(own_slots, mm),
+                                              (unsigned long long) bget(&my->res_samples[e * RIM_GROUP + mm]));
+                    }
+                }
+#pragma unroll
+                for (int mm = 0; mm < RIM_GROUP; mm++) {
+                    const int stl = sel4(mm, st_l0, st_l1, st_l2, st_l3);
+                    int bst = 0;
+                    if (wv_ballot((stl & ST_INNER_FAIL) != 0)) bst |= ST_INNER_FAIL;
+                    if (wv_ballot((stl & ST_STORE_FULL) != 0)) bst |= ST_STORE_FULL;
+                    put4(mm, bst, bs0, bs1, bs2, bs3);
+                }
+            } else {
+                // a claimed entry has not come back within the bound: the owner closes the round, evaluates ALL of it
+                // itself (same bits, only later; nothing of the failed attempt has been booked) and never publishes again
+                board_dead = true;
+                shared = false;
+                gv0 = gv1 = gv2 = gv3 = 0.;
+                bs0 = bs1 = bs2 = bs3 = 0;
+                redo = true;
+            }
+        }
+        } while (redo);
+        if (helper) {
+            if (got == 0) {
+                for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
+                if (backoff < 16) backoff *= 2;
+            } else {
+                if (lane == 0) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                counted_idle = true;
+            }
+            continue;
+        }
+        __syncthreads();
+        // ---------- every member that posted consumes its results ----------
+        for (unsigned rem = posted; rem; rem &= rem - 1) {
+            const int m = __builtin_ctz(rem);
+            SymPoint pt = pt0;
+            pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
+            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+            TaskState T = s_park[m];
+            task_uniformize(T);
+            SymBatch B;
+            B.req_n = sel4(m, rq0, rq1, rq2, rq3);
+            B.req_lobe = sel4(m, rl0, rl1, rl2, rl3);
+            B.req_active = ((act >> m) & 1u) != 0;
+            B.n_req = sel4(m, nq0, nq1, nq2, nq3);
+            B.phase = sel4(m, ph0, ph1, ph2, ph3);
+            sym_consume(pt, g, outer, T, B, sel4(m, gv0, gv1, gv2, gv3), uni(sel4(m, bs0, bs1, bs2, bs3)));
+            __syncthreads();
+            if (lane == 0) s_park[m] = T;
+            if (T.phase == PH_DONE) alive &= ~(1u << m);
+        }
+        __syncthreads();
+    }
+
+    __syncthreads();
+    if (g.lane == 0) {
+        atomicAdd(queue + 1, s_gp.ctr.samples);
+        atomicAdd(queue + 2, s_gp.ctr.steps);
+        atomicAdd(queue + 3, s_gp.ctr.inner_qags);
+        atomicAdd(a.queue + 8, s_gp.member_passes);
+        atomicAdd(a.queue + 9, s_gp.stash_filed);
+    }
+}
+
+// ---- launch interface (group_launch.h) -----------------------------------------------------------------------
+template <int KIND>
+static const void *kernel_ptr() { return reinterpret_cast<const void *>(group_kernel<KIND>); }
+
+const void *rim_group_kernel(int kind)
+{
+    switch (kind) {
+    case 0: return kernel_ptr<0>();
+    case 1: return kernel_ptr<1>();
+    case 2: return kernel_ptr<2>();
+    default: return kernel_ptr<3>();
+    }
+}
+
+int rim_group_launch(int kind, unsigned grid, hipStream_t st, const GroupArgs &ga)
+{
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(group_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
+    case 1: hipLaunchKernelGGL(group_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
+    case 2: hipLaunchKernelGGL(group_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
+    default: hipLaunchKernelGGL(group_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
+    }
+    return hipGetLastError() == hipSuccess ? RIMPHONY_OK : RIMPHONY_EHIP;
+}

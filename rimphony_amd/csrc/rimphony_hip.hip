@@ -33,6 +33,8 @@
 using namespace rim;
 
 #include "rimphony_internal.h"
+#include "coop_common.h"
+#include "group_launch.h"
 
 // ------------------------------------------------------------------------------
 // normalisation integrands (power_law.rs:95-96, pitchy_kappa.rs:100-104; the
@@ -63,34 +65,6 @@ __device__ inline double hyperg_2F1_at_1(double a, double b, double c)
     const double lca = rim_lgamma_pos(c - a);
     const double lcb = rim_lgamma_pos(c - b);
     return rim_exp(lc + lcab - lca - lcb);
-}
-
-struct ParamPtrs { const double *p[5]; };
-struct AssistSlot;
-
-template <int KIND>
-__device__ inline void load_params(const ParamPtrs &pp, size_t i, DistParams &d)
-{
-    constexpr int NP = (KIND == DIST_POWER_LAW) ? 4 : (KIND == DIST_THERMAL_JUETTNER) ? 1 : (KIND == DIST_PITCHY_PL) ? 5 : 4;
-#pragma unroll
-    for (int k = 0; k < 5; k++) d.par[k] = (k < NP) ? pp.p[k][i] : 0.;
-}
-
-// Fetch the next task index for the whole wave.  The two barriers are not for
-// memory ordering: they are convergent operations that pin the reconvergence
-// point of the surrounding `if (lane == 0)` regions.  Without them LLVM threads
-// the lane-0-only epilogue of one loop iteration straight into the lane-0-only
-// atomic of the next, the structurizer then builds a separate inner cycle for
-// lanes 1..63, and those lanes run ahead of lane 0, read t from their own first
-// lane (always 0) and re-execute task 0 forever (observed on gfx950, ROCm 7.2).
-__device__ __forceinline__ unsigned long long wave_next_task(unsigned long long *queue, int lane)
-{
-    __syncthreads();
-    unsigned long long t = 0;
-    if (lane == 0) t = atomicAdd(queue, 1ull);
-    __syncthreads();
-    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (t >> 32)) << 32) |
-           (unsigned) __builtin_amdgcn_readfirstlane((int) (t & 0xffffffffull));
 }
 
 template <int KIND>
@@ -137,157 +111,10 @@ __global__ __launch_bounds__(64) void norm_kernel(ParamPtrs pp, size_t n, double
 // symphony
 // ------------------------------------------------------------------------------
 
-struct SymArgs {
-    ParamPtrs pp;
-    const double *s, *theta, *norm;
-    double *out;
-    int32_t *status;
-    size_t n;
-    int nslots;
-    int slot[8];
-    unsigned long long *queue;      // [0] task head, [1] samples, [2] passes, [3] inner qags
-    const unsigned *perm;           // task order (expensive points first) or null
-    double *spill;                  // [gridDim.x][SPILL_DOUBLES_PER_WAVE] wave-private global store overflow
-    struct AssistSlot *board;       // [gridDim.x] cooperative-tail board (null: cooperation off)
-    unsigned *board_flags;          // [0] task queue exhausted, [1] waves that still own / may fetch a task
-    const double *series_tab;       // Heyvaerts: divisors of the fixed-order Bessel series and their reciprocals
-    unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
-    unsigned long long hb_task;
-    unsigned long long *work;       // optional [n][8]: integrand samples spent on each coefficient (null: not counted)
-    unsigned long long idle_ticks;  // wall_clock64 ticks after which a helper that has found nothing leaves (2 s)
-    unsigned long long owner_ticks; // ... after which an owner stops waiting for helpers and recomputes its batch (120 s)
-};
-
 #if defined(RIM_PROF)
 #define RIM_PROF_ROWS 32768
 __device__ unsigned long long g_rim_prof[RIM_PROF_ROWS * 32];
 #endif
-
-__constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
-__constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
-
-// ---- cooperative tail: the assist board ---------------------------------------------------
-//
-// Per-task cost has a heavy tail (rare points are 100-1000x the mean; the reference prints
-// "SLOW" for them).  With one wave per task, the end of a launch would be a few waves grinding
-// through such tasks while the rest of the chip idles.  Once the task queue has run dry and some
-// wave is idle, a wave that still owns a task therefore PUBLISHES each batch of (n, lobe) requests
-// of its state machine on its slot of a board in global memory, and waves without a task claim
-// individual requests, evaluate the gamma-integral and write the value back.  Every request is a
-// pure function of (point, coefficient, n, lobe), so who evaluates it cannot change a bit of the
-// result.
-//
-// Protocol (placement-independent, agent-scope release/acquire, every spin bounded):
-//   slot.claim = (seq << 32) | (count << 8) | next        open iff next < count
-//   owner:  write the compacted requests (sc1 stores) -> s_waitcnt vmcnt(0) ->
-//           claim = (seq << 32) | (count << 8); advertise the slot in one of 64 hint words
-//   anyone: c = load(claim); if next(c) < count(c): CAS(claim, c, c + 1) claims request next(c).
-//           A successful CAS proves batch `seq` was still open, so the request data (read with sc1
-//           loads) belonged to it and stays valid until this claimer reports `done`.
-//   result: res[k], status[k] (sc1 stores) -> s_waitcnt vmcnt(0) -> atomicAdd(done)
-//   owner:  poll done == count -> read res[] (sc1 loads) -> claim = (seq << 32) (closed)
-// Discovery: there are 64 hint lines; an idle wave polls ONE of them (its index mod 64: one sc1 load
-// per poll, with exponential back-off) and looks at a slot's claim word only when the hint it
-// sees has changed.  An owner advertises a batch on every hint line of one "channel"
-// (line & (span - 1) == channel), where span ~ the number of waves that still own a task: with
-// 100 owners each batch is seen by 1/64 of the idle waves, with 2 owners by half of them, yet the
-// polls stay spread over 64 lines.  (All waves polling the same few lines -- and a per-poll look at
-// the claim word -- was measured to slow the computing waves several-fold.)
-// Idle waves count themselves in flags[IDLE] so that owners publish only when somebody can help.
-struct AssistSlot {
-    unsigned long long claim;
-    unsigned long long point;
-    unsigned done;
-    int slot;
-    unsigned long long req_n[64];     // bit patterns of doubles: every access is an agent-scope atomic
-    unsigned long long res[64];
-    int req_lobe[64];
-    int res_status[64];
-};
-
-// Board payload accessors: relaxed agent-scope atomics = sc1 (write-through / L1-bypassing) stores
-// and loads.  Thousands of waves use the board at the same time at the end of a launch; agent-scope
-// release/acquire FENCES there (an L2 write-back + L1 invalidate each) serialise on the XCD's L2 and
-// cost more than the work being shared, so the hand-off uses write-through granules instead:
-// sc1 stores -> s_waitcnt vmcnt(0) -> counter/flag atomic on the producer, sc1 loads after the
-// poll on the consumer (MI355X_MICROARCH.md, "Valid forms").
-__device__ __forceinline__ void bput(unsigned long long *p, unsigned long long v)
-{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void bput(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void bput(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long bget(const unsigned long long *p)
-{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int bget(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned bget(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Flag words; each lives in its own 128-byte line, because thousands of waves poll them.
-#define BOARD_FLAG_EXHAUSTED 0
-#define BOARD_FLAG_ACTIVE 32
-#define BOARD_FLAG_IDLE 64
-#define BOARD_HINTS 96          // 64 hint lines (stride 32 words): (seq << 16) | (slot + 1) of a published batch
-#define BOARD_HINT_STRIDE 32
-#define BOARD_FLAG_WORDS (BOARD_HINTS + 64 * BOARD_HINT_STRIDE)
-
-__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v)
-{
-    return ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (v >> 32)) << 32) |
-           (unsigned) __builtin_amdgcn_readfirstlane((int) (v & 0xffffffffull));
-}
-
-// Number of hint words in use (power of two <= 64): about one per wave that still owns a task, so
-// that each published batch is seen by (idle waves / owners) helpers.
-__device__ __forceinline__ unsigned hint_span(unsigned active)
-{
-    unsigned h = 1;
-    while (h < 64u && h * 2u <= active) h *= 2u;
-    return h;
-}
-
-__device__ __forceinline__ bool claim_open(unsigned long long c) { return (unsigned) (c & 0xff) < (unsigned) ((c >> 8) & 0xff); }
-
-// Claim the next unevaluated request of batch `seq` on `slot`; -1 if there is none (or the batch is over).
-__device__ __forceinline__ int assist_claim(AssistSlot *slot, unsigned seq, int lane)
-{
-    int k = -1;
-    if (lane == 0) {
-        for (int tries = 0; tries < 64; tries++) {
-            const unsigned long long c = __hip_atomic_load(&slot->claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned) (c >> 32) != seq || !claim_open(c)) break;
-            unsigned long long expect = c;
-            if (__hip_atomic_compare_exchange_strong(&slot->claim, &expect, c + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) { k = (int) (c & 0xff); break; }
-        }
-    }
-    return __builtin_amdgcn_readfirstlane(k);
-}
-
-__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// lane index of the k-th set bit of mask (k < popcount(mask))
-__device__ __forceinline__ int kth_set_bit(unsigned long long mask, int k)
-{
-    for (int i = 0; i < k; i++) mask &= mask - 1;
-    return __builtin_ffsll((long long) mask) - 1;
-}
-
-template <int KIND>
-__device__ __forceinline__ void load_context(const SymArgs &a, size_t i, int slot, SymPoint &pt, DistParams &d, double &norm)
-{
-    pt.s = uni(a.s[i]);
-    rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
-    pt.sin_th = uni(pt.sin_th);
-    pt.cos_th = uni(pt.cos_th);
-    pt.coeff = uni(c_slot_coeff[slot]);
-    pt.stokes = uni(c_slot_stokes[slot]);
-    load_params<KIND>(a.pp, i, d);
-    norm = uni(a.norm[i]);
-    dist_prepare<KIND>(d, norm);
-#pragma unroll
-    for (int k = 0; k < 5; k++) d.par[k] = uni(d.par[k]);
-    d.inv_gamma_cutoff = uni(d.inv_gamma_cutoff);
-    d.inv_kappa_width = uni(d.inv_kappa_width);
-    d.neg_inverse_t = uni(d.neg_inverse_t);
-}
 
 // ---- the two problems the cooperative kernel runs ------------------------------------------
 // A problem supplies the uniform context of a task, the parked task state and the five steps of
@@ -982,7 +809,14 @@ struct rimphony_ctx {
     // work (ev_batch), and the calls themselves are serialised by mu
     hipEvent_t ev_batch;
     int ev_batch_valid;
-    std::mutex *mu;
+    std::recursive_mutex *mu;
+    // group kernel (rimphony_group.hip): per-wave spill regions and board, resident workgroups per CU by kind
+    double *d_gspill;
+    size_t gspill_waves;
+    GroupSlot *d_gboard;            // [gboard_slots] + flag words behind
+    size_t gboard_slots;
+    int resident_group[4];
+    int sym_solo;                   // RIMPHONY_SYM_SOLO=1: one wave per (point, coefficient), the round-2 kernel (A/B measurements)
 };
 
 // ---- last error (thread-local text; the codes are in rimphony_hip.h) ---------------------------
@@ -992,6 +826,10 @@ void rim_set_last_error(const char *what, const char *detail)
     snprintf(t_last_error, sizeof t_last_error, "%s: %s", what ? what : "?", detail ? detail : "?");
 }
 extern "C" const char *rimphony_last_error(void) { return t_last_error; }
+void rim_clear_last_error() { t_last_error[0] = 0; }
+
+void rim_ctx_lock(rimphony_ctx *c) { c->mu->lock(); }
+void rim_ctx_unlock(rimphony_ctx *c) { c->mu->unlock(); }
 
 static const int NPARAMS[4] = { 4, 1, 5, 4 };
 
@@ -1031,9 +869,14 @@ static int take_device_lock(int device, int *fd_out)
     for (char *q = bus; *q; q++) if (*q == ':' || *q == '/') *q = '_';
     char path[160];
     snprintf(path, sizeof path, "/dev/shm/rimphony_hip.%s.lock", bus);
-    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    // /dev/shm is world-writable: never follow a planted symlink, only lock a regular file, and only widen the mode of
+    // a file this process has just created (O_EXCL), so that another user's context can open it later.
+    int fd = open(path, O_CREAT | O_EXCL | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+    if (fd >= 0) (void) fchmod(fd, 0666);
+    else fd = open(path, O_RDWR | O_CLOEXEC | O_NOFOLLOW);
     if (fd < 0) return 0;                       // cannot tell: assume the device is ours
-    (void) fchmod(fd, 0666);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return 0; }
     if (flock(fd, LOCK_EX | LOCK_NB) == 0) { *fd_out = fd; return 0; }
     close(fd);
     return 1;                                   // somebody else holds it
@@ -1047,6 +890,8 @@ static void ctx_free(rimphony_ctx *c)
     if (c->d_perm) (void) hipFree(c->d_perm);
     if (c->d_spill) (void) hipFree(c->d_spill);
     if (c->d_board) (void) hipFree(c->d_board);
+    if (c->d_gspill) (void) hipFree(c->d_gspill);
+    if (c->d_gboard) (void) hipFree(c->d_gboard);
     if (c->d_in) (void) hipFree(c->d_in);
     if (c->d_out) (void) hipFree(c->d_out);
     if (c->d_status) (void) hipFree(c->d_status);
@@ -1076,9 +921,10 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     memset(c, 0, sizeof *c);
     c->device = device;
     c->lock_fd = -1;
-    c->mu = new (std::nothrow) std::mutex();
+    c->mu = new (std::nothrow) std::recursive_mutex();
     if (!c->mu) { delete c; return RIMPHONY_ENOMEM; }
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
+    { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
     c->shared_mode = take_device_lock(device, &c->lock_fd);
     if (c->shared_mode) {
         const char *e = getenv("RIMPHONY_EXCLUSIVE");
@@ -1122,6 +968,19 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
 }
 
 extern "C" int rimphony_ctx_shared_mode(const rimphony_ctx *c) { return c ? c->shared_mode : RIMPHONY_EINVAL; }
+
+int rim_ctx_enter(rimphony_ctx *c, hipStream_t st)
+{
+    rim_clear_last_error();
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->ev_batch_valid) HIP_TRY(hipStreamWaitEvent(st, c->ev_batch, 0));
+    return RIMPHONY_OK;
+}
+void rim_ctx_leave(rimphony_ctx *c, hipStream_t st)
+{
+    // also after a failure part-way: whatever was enqueued must finish before the workspace is reused
+    if (hipEventRecord(c->ev_batch, st) == hipSuccess) c->ev_batch_valid = 1;
+}
 
 static int ensure_spill(rimphony_ctx *c, size_t waves)
 {
@@ -1194,8 +1053,10 @@ extern "C" int rimphony_batch_norm_device(rimphony_ctx *c, int kind, size_t n, c
     ParamPtrs pp;
     int rc = make_param_ptrs(kind, d_params, pp);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);
+    rc = scope.enter();
+    if (rc) return rc;
     switch (kind) {
     case 0: return launch_norm<0>(c, n, pp, d_norm, st);
     case 1: return launch_norm<1>(c, n, pp, d_norm, st);
@@ -1279,6 +1140,79 @@ static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     return rc;
 }
 
+// The Symphony slots of a batch as (point, group) tasks: group 0 = the selected ones of {j_I, alpha_I, j_Q, alpha_Q},
+// group 1 = those of {j_V, alpha_V} (rimphony_group.hip / symphony_group.h).
+static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t coeff_mask, hipStream_t st)
+{
+    GroupArgs ga;
+    ga.base = a;
+    ga.ngroups = 0;
+    ga.gslots[0] = ga.gslots[1] = 0;
+    ga.gnmem[0] = ga.gnmem[1] = 0;
+    for (int grp = 0; grp < 2; grp++) {
+        unsigned packed = 0;
+        int nm = 0;
+        for (int k = grp ? 4 : 0; k < (grp ? 6 : 4); k++)
+            if (coeff_mask & (1u << k)) { packed |= (unsigned) k << (4 * nm); nm++; }
+        if (nm) { ga.gslots[ga.ngroups] = packed; ga.gnmem[ga.ngroups] = nm; ga.ngroups++; }
+    }
+    if (ga.ngroups == 0) return RIMPHONY_OK;
+    const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) ga.ngroups;
+    const unsigned long long want_waves = (ntasks > (1ull << 40) || c->no_assist) ? ntasks : ntasks * 64ull;
+    int *resident = &c->resident_group[kind];
+    const void *kfn = rim_group_kernel(kind);
+    if (*resident == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 64, RIM_DYN_LDS) != hipSuccess || nb < 1) nb = 4;
+        *resident = nb < 4 * RIM_GROUP_WAVES ? nb : 4 * RIM_GROUP_WAVES;
+    }
+    int resident_per_cu = *resident;
+    {   // the LDS limit re-derived with the 512-byte allocation granule and one granule of slack (see launch_coop)
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, kfn) == hipSuccess) {
+            const size_t lds = ((fa.sharedSizeBytes + RIM_DYN_LDS + 511) / 512) * 512;
+            if (lds > 0) {
+                const int by_lds = (int) ((160 * 1024 - 512) / lds);
+                if (by_lds >= 1 && by_lds < resident_per_cu) resident_per_cu = by_lds;
+            }
+        }
+    }
+    if (c->shared_mode) resident_per_cu = resident_per_cu >= 8 ? resident_per_cu / 4 : 2;
+    const unsigned grid = persistent_grid(c, want_waves, resident_per_cu);
+    if (c->gspill_waves < grid) {
+        if (c->d_gspill) (void) hipFree(c->d_gspill);
+        c->d_gspill = nullptr;
+        c->gspill_waves = 0;
+        if (hipMalloc(&c->d_gspill, (size_t) grid * SPILL_GROUP_DOUBLES_PER_WAVE * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+        c->gspill_waves = grid;
+    }
+    if (c->gboard_slots < grid) {
+        if (c->d_gboard) (void) hipFree(c->d_gboard);
+        c->d_gboard = nullptr;
+        c->gboard_slots = 0;
+        if (hipMalloc(&c->d_gboard, (size_t) grid * sizeof(GroupSlot) + BOARD_FLAG_WORDS * sizeof(unsigned)) != hipSuccess)
+            return RIMPHONY_ENOMEM;
+        c->gboard_slots = grid;
+    }
+    ga.gspill = c->d_gspill;
+    ga.gboard = c->d_gboard;
+    ga.coop = c->no_assist ? 0 : 1;
+    ga.base.board = nullptr;
+    ga.base.board_flags = (unsigned *) (c->d_gboard + c->gboard_slots);
+    ga.base.idle_ticks = 2ull * c->ticks_per_s;
+    ga.base.owner_ticks = c->owner_wait_ticks;
+    // every claim word starts closed; flags: not exhausted, `grid` active waves, nobody idle (the payload arrays of the
+    // slots need no reset: an entry is written before its round is opened)
+    HIP_TRY(hipMemset2DAsync(c->d_gboard, sizeof(GroupSlot), 0, 32, grid, st));
+    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, ga.base.board_flags, grid);
+    HIP_TRY(hipEventRecord(c->ev_start, st));
+    const int rc = rim_group_launch(kind, grid, st, ga);
+    if (rc) { rim_set_last_error("group_kernel launch", hipGetErrorString(hipGetLastError())); return rc; }
+    HIP_TRY(hipEventRecord(c->ev_stop, st));
+    c->ev_valid = 1;
+    return RIMPHONY_OK;
+}
+
 // The batch entry points share the context's workspace (task queue, norms, visiting order, spill regions, assist
 // board, timing events).  Calls on one context are therefore serialised on the host (c->mu) and ordered on the device:
 // a call's stream first waits for the event the previous call recorded after its last kernel, whatever stream that was.
@@ -1295,14 +1229,11 @@ extern "C" int rimphony_batch_compute_device_ex(rimphony_ctx *c, int kind, size_
     if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
     if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
-    std::lock_guard<std::mutex> lock(*c->mu);
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
-    if (c->ev_batch_valid) HIP_TRY(hipStreamWaitEvent(st, c->ev_batch, 0));
-    const int rc = batch_compute_locked(c, kind, n, d_s, d_theta, d_params, coeff_mask, precision, d_out, d_status, d_work, st);
-    // also after a failure part-way: whatever was enqueued must finish before the workspace is reused
-    if (hipEventRecord(c->ev_batch, st) == hipSuccess) c->ev_batch_valid = 1;
-    return rc;
+    RimCtxScope scope(c, st);
+    int rc = scope.enter();
+    if (rc) return rc;
+    return batch_compute_locked(c, kind, n, d_s, d_theta, d_params, coeff_mask, precision, d_out, d_status, d_work, st);
 }
 
 extern "C" int rimphony_batch_compute_device(rimphony_ctx *c, int kind, size_t n,
@@ -1392,6 +1323,9 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
             case 2: rc = launch_symphony<2, 1>(c, a, st); break;
             default: rc = launch_symphony<3, 1>(c, a, st); break;
             }
+        } else if (!c->sym_solo) {
+            // the coefficients of a point that share their samples advance in lock-step on one wave
+            rc = launch_group(c, kind, a, coeff_mask, st);
         } else {
             switch (kind) {
             case 0: rc = launch_symphony<0>(c, a, st); break;
@@ -1498,11 +1432,16 @@ extern "C" int rimphony_batch_compute_ex(rimphony_ctx *c, int kind, size_t n,
     if (!s || !theta) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];
     for (int k = 0; k < np; k++) if (!params[k]) return RIMPHONY_EINVAL;
+    // ONE lock across staging, launch, synchronisation and copy-out: the staging buffers belong to the context, and a
+    // second thread on the same context must not overwrite or re-allocate them before this call has copied its
+    // table out (include/rimphony_hip.h: "Calls on one context are serialised").  The device entry below re-locks
+    // the same (recursive) mutex.
+    RimCtxScope scope(c, nullptr);
+    rim_clear_last_error();
     HIP_TRY(hipSetDevice(c->device));
     const double *dp[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     uint64_t *d_work = nullptr;
     {
-        std::lock_guard<std::mutex> lock(*c->mu);
         if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));   // the staging buffers may still be in use
         const size_t need_in = n * (size_t) (2 + np);
         if (c->in_cap < need_in) {
@@ -1646,7 +1585,8 @@ extern "C" int rimphony_status_histogram_device(rimphony_ctx *c, size_t n, const
     for (int k = 0; k < 64; k++) hist[k] = 0;
     if (n == 0) return RIMPHONY_OK;
     if (!d_status) return RIMPHONY_EINVAL;
-    std::lock_guard<std::mutex> lock(*c->mu);
+    std::lock_guard<std::recursive_mutex> lock(*c->mu);
+    rim_clear_last_error();
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
     // the histogram words live behind the counter words of the queue allocation? no: they are read back here, so a
@@ -1679,7 +1619,12 @@ extern "C" int rimphony_highfreq_batch(rimphony_ctx *c, int kind, size_t n, cons
     if (kind != RIMPHONY_POWER_LAW && kind != RIMPHONY_THERMAL_JUETTNER) return RIMPHONY_EINVAL;
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta || !out) return RIMPHONY_EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    RimCtxScope scope(c, nullptr);
+    {
+        const int rc0 = scope.enter();
+        if (rc0) return rc0;
+        if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));   // the staging buffer may still be in use
+    }
     const int np = kind == RIMPHONY_POWER_LAW ? 2 : 1;       // only p and gamma_min (or T) enter the closed forms
     for (int k = 0; k < np; k++) if (!params[k]) return RIMPHONY_EINVAL;
     const size_t need_in = n * (size_t) (2 + np + 2);
@@ -1784,8 +1729,10 @@ extern "C" int rimphony_gamma_integrand_batch_device(rimphony_ctx *c, int kind, 
     int rc = fill_point_args(kind, params, coeff, stokes, 0, s, theta, pa);
     if (rc) return rc;
     if (count == 0) return RIMPHONY_OK;
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);
+    rc = scope.enter();
+    if (rc) return rc;
     rc = single_point_norm(c, kind, params, st);
     if (rc) return rc;
     const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
@@ -1826,8 +1773,10 @@ extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, c
     int rc = fill_point_args(kind, params, coeff, stokes, negative_lobe, s, theta, pa);
     if (rc) return rc;
     if (count == 0) return RIMPHONY_OK;
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);
+    rc = scope.enter();
+    if (rc) return rc;
     rc = single_point_norm(c, kind, params, st);
     if (rc) return rc;
     const unsigned grid = persistent_grid(c, count, 16);
@@ -1876,7 +1825,7 @@ extern "C" int rimphony_detmath_batch_device(rimphony_ctx *c, int op, size_t n, 
 {
     if (!c || op < 0 || op > 14) return RIMPHONY_EINVAL;
     if (n == 0) return RIMPHONY_OK;
-    if (!d_x || !d_out || ((op == 3 || op == 9) && !d_y)) return RIMPHONY_EINVAL;
+    if (!d_x || !d_out || ((op == 3 || op == 9 || op == 12 || op == 14) && !d_y)) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(detmath_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, op, n, d_x, d_y, d_out);
     HIP_TRY(hipGetLastError());
@@ -1927,9 +1876,11 @@ extern "C" int rimphony_qag_selftest_device(rimphony_ctx *c, size_t count, const
         return RIMPHONY_EINVAL;
     if (limit < 1) return RIMPHONY_EINVAL;
     if (count == 0) return RIMPHONY_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    RimCtxScope scope(c, (hipStream_t) stream);
+    int rc = scope.enter();
+    if (rc) return rc;
     const unsigned grid = persistent_grid(c, count, 16);
-    int rc = ensure_spill(c, grid);
+    rc = ensure_spill(c, grid);
     if (rc) return rc;
     hipLaunchKernelGGL(qag_selftest_kernel, dim3(grid), dim3(64), 0, (hipStream_t) stream, count, d_family, d_p0, d_p1,
                        d_a, d_b, epsabs, epsrel, (int) limit, d_result, d_abserr, d_qstatus, d_size, c->d_spill);

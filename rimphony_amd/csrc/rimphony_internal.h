@@ -63,6 +63,26 @@ int rim_point_setup(rimphony_ctx *c, int kind, const double *params, int coeff, 
                     double s, double theta, hipStream_t st, PointArgs &pa);
 // persistent grid of single-wave workgroups for `count` work items + its per-wave spill region
 int rim_wave_grid(rimphony_ctx *c, size_t count, int waves_per_cu, unsigned *grid);
+// Every entry point that touches the context's workspace (norms, spill regions, staging buffers, queue words) runs
+// inside one of these: the context's (recursive) host lock for the whole call -- staging, launches, synchronisation and
+// copy-out included --, the device selected, `st` ordered behind the previous call's work on the workspace, and that
+// call's own last kernel recorded for the next one when the scope ends.  enter() also forgets the thread's previous
+// error text, so that rimphony_last_error() never describes an older call.
+void rim_ctx_lock(rimphony_ctx *c);
+void rim_ctx_unlock(rimphony_ctx *c);
+int rim_ctx_enter(rimphony_ctx *c, hipStream_t st);
+void rim_ctx_leave(rimphony_ctx *c, hipStream_t st);
+void rim_clear_last_error();
+struct RimCtxScope {
+    rimphony_ctx *c;
+    hipStream_t st;
+    bool entered;
+    RimCtxScope(rimphony_ctx *ctx, hipStream_t stream) : c(ctx), st(stream), entered(false) { rim_ctx_lock(c); }
+    int enter() { const int rc = rim_ctx_enter(c, st); entered = (rc == 0); return rc; }
+    ~RimCtxScope() { if (entered) rim_ctx_leave(c, st); rim_ctx_unlock(c); }
+    RimCtxScope(const RimCtxScope &) = delete;
+    RimCtxScope &operator=(const RimCtxScope &) = delete;
+};
 const double *rim_ctx_norm(const rimphony_ctx *c);
 double *rim_ctx_spill(const rimphony_ctx *c);
 

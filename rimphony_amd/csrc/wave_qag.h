@@ -10,11 +10,17 @@
 //     registers (loaded once from the LDS copy of the table).
 //   * A bisection evaluates BOTH children in one pass: left child on lanes
 //     0..31, right child on lanes 32..63 (62 of 64 lanes busy).
-//   * The four rule sums (Kronrod, Gauss, |f|, |f - mean|) are 5-step xor
-//     butterflies inside each half-wave (ds_swizzle, bit-mask mode).  Floating-point addition commutes, so
-//     every lane of a half ends with the same bits: the value of a fixed
-//     balanced binary tree over the 32 lanes.  The CPU oracle sums in the same
-//     tree order, which is what makes results comparable bit for bit.
+//   * The four rule sums (Kronrod, Gauss, |f|, |f - mean|) are formed from QUADPACK's own terms: the two nodes
+//     +-xgk[k] of the rule sit on ADJACENT lanes (2k, 2k + 1; lane 30 is the centre, lane 31 padding), so the first
+//     butterfly step (ds_swizzle xor 1) is qk.c's pair sum f1 + f2, the product with the pair's weight follows, and four
+//     more steps (xor 2, 4, 8, 16) add the 16 terms w (f1 + f2).  Floating-point addition commutes, so every lane of
+//     a half ends with the same bits: the value of a fixed balanced binary tree over the 16 terms.  The CPU oracle
+//     forms the same terms and adds them in the same tree, which is what makes results comparable bit for bit.
+//     (Until round 3 the kernels summed 32 per-NODE products w f.  Far out in the harmonic tail the samples are
+//     subnormal -- a few quanta of 2^-1074 -- and every product rounds to whole quanta: per-node products of small
+//     samples vanish where the reference's pair terms survive, GSL's round-off detectors saw systematically different
+//     error estimates, and 1 % of the thermal coefficients were NaN here and numbers in the reference's arithmetic.
+//     With the reference's terms the sums of subnormal samples are exact in any order: DESIGN.md section 2.)
 //   * The subinterval list (alist/blist/rlist/elist of the GSL workspace) lives
 //     in LDS, wave-private.  GSL's sorted `order` list is replaced by a
 //     wave-wide argmax over (error, insertion stamp): GSL inserts a new entry
@@ -95,13 +101,23 @@ __constant__ double c_gk_wk[32] = RIM_GK31_WK;
 __constant__ double c_gk_wg[32] = RIM_GK31_WG;
 
 struct GKLane {
-    const double *tab;  // LDS image of the rule: [0..31] abscissae, [32..63] Kronrod weights, [64..95] Gauss weights
+    const double *tab;  // LDS image of the rule IN LANE ORDER: [0..31] abscissae, [32..63] Kronrod weights, [64..95] Gauss weights
     int lane, half, j;
     bool node;          // j < 31
 };
 __device__ __forceinline__ double gk_t(const GKLane &g) { return g.tab[g.j]; }
 __device__ __forceinline__ double gk_wk(const GKLane &g) { return g.tab[32 + g.j]; }
 __device__ __forceinline__ double gk_wg(const GKLane &g) { return g.tab[64 + g.j]; }
+
+// Node of the ascending table (gk31_table.h) that lane j of a half-wave evaluates: lanes 2k and 2k + 1 hold the
+// symmetric pair -xgk[k], +xgk[k] (table entries k and 30 - k), lane 30 the centre.  Lane 31 is padding: it never
+// evaluates the integrand (GKLane::node is false, its sample counts as 0), but it carries the CENTRE's weights, so
+// that both lanes of the last pair hold the same term w_c (f_c + 0) and every lane of a half-wave ends with the same
+// rule sums (with a zero weight there the odd lanes would miss the centre term).
+__device__ __forceinline__ int gk_node_of_lane(int j)
+{
+    return j >= 30 ? 15 : ((j & 1) ? 30 - (j >> 1) : (j >> 1));
+}
 
 // LDS image of the rule + per-lane registers.  tab must hold 96 doubles.
 __device__ __forceinline__ GKLane gk_lane_init(double *tab)
@@ -112,9 +128,10 @@ __device__ __forceinline__ GKLane gk_lane_init(double *tab)
     g.j = g.lane & 31;
     g.node = g.j < 31;
     if (g.lane < 32) {
-        tab[g.lane] = c_gk_x[g.lane];
-        tab[32 + g.lane] = c_gk_wk[g.lane];
-        tab[64 + g.lane] = c_gk_wg[g.lane];
+        const int node = gk_node_of_lane(g.lane);
+        tab[g.lane] = c_gk_x[node];
+        tab[32 + g.lane] = c_gk_wk[node];
+        tab[64 + g.lane] = c_gk_wg[node];
     }
     wv_sync();
     g.tab = tab;
@@ -141,10 +158,11 @@ __device__ __forceinline__ double uni(double v)
 __device__ __forceinline__ int uni(int v) { return wv_readfirstlane(v); }
 __device__ __forceinline__ bool uni(bool v) { return wv_readfirstlane((int) v) != 0; }
 
-// Sum over the 32 lanes of each half-wave; all lanes of a half receive the sum.
-__device__ __forceinline__ double half_sum(double v)
+// The rule sums: v + (value of the other node of the pair) is qk.c's f1 + f2 ...
+__device__ __forceinline__ double pair_sum(double v) { return v + wv_swz_xor<1>(v); }
+// ... and the 16 weighted pair terms (both lanes of a pair hold the same term) are added over the pairs of a half-wave.
+__device__ __forceinline__ double sum16(double v)
 {
-    v = v + wv_swz_xor<1>(v);
     v = v + wv_swz_xor<2>(v);
     v = v + wv_swz_xor<4>(v);
     v = v + wv_swz_xor<8>(v);
@@ -175,11 +193,13 @@ __device__ __forceinline__ double rescale_error(double err, double result_abs, d
 __device__ __forceinline__ GKRes wave_gk31(double fv, double half_length, const GKLane &g)
 {
     const double wk = gk_wk(g);
-    double rk = half_sum(wk * fv);
-    const double rg = half_sum(gk_wg(g) * fv);
-    double ra = half_sum(wk * rim_fabs(fv));
+    const double fsum = pair_sum(fv);                                  // qk.c: fsum = fval1 + fval2 (centre: fc + 0)
+    double rk = sum16(wk * fsum);
+    const double rg = sum16(gk_wg(g) * fsum);
+    double ra = sum16(wk * pair_sum(rim_fabs(fv)));
     const double mean = rk * 0.5;
-    double rasc = half_sum(wk * rim_fabs(fv - mean));
+    const double dev = g.node ? rim_fabs(fv - mean) : 0.;              // the padding lane holds 0, not |0 - mean|
+    double rasc = sum16(wk * pair_sum(dev));
     const double ahl = rim_fabs(half_length);
     const double err = (rk - rg) * half_length;
     rk *= half_length;

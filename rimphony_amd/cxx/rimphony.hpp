@@ -46,7 +46,8 @@ inline void check(int rc, const char *what)
 {
     if (rc == RIMPHONY_OK) return;
     std::string msg = std::string(what) + ": " + rimphony_strerror(rc);
-    const char *detail = rimphony_last_error();          // the HIP call that failed, if any (thread-local)
+    // the HIP call that failed (thread-local text): only a RIMPHONY_EHIP return is described by it
+    const char *detail = rc == RIMPHONY_EHIP ? rimphony_last_error() : nullptr;
     if (detail && *detail) msg += std::string(" -- ") + detail;
     throw std::runtime_error(msg);
 }

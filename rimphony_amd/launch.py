@@ -40,19 +40,31 @@ def spawn_ranks(n, argv=None, extra_env=None, timeout=None):
         # ranks other than 0 keep stderr, drop stdout: the contract is ONE line on stdout
         out = None if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=out))
+    # Poll ALL children: whichever rank dies first (a bad device, a failed init), the others would sit in
+    # init_process_group or a barrier until the collective's own timeout (10-30 minutes) -- they are ended as soon as
+    # any child has exited non-zero.  `timeout` is one deadline for the whole run, not per child.
+    import time
     worst = 0
-    try:
-        for p in procs:
-            rc = p.wait(timeout=timeout)
+    deadline = None if timeout is None else time.monotonic() + timeout
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
             if rc != 0 and worst == 0:
                 worst = rc if rc > 0 else 1
-                # one rank failed: the others would wait in a collective forever
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
-    except subprocess.TimeoutExpired:
-        worst = 124
-        for q in procs:
-            if q.poll() is None:
+                for q in live:
+                    q.terminate()
+        if not live:
+            break
+        if deadline is not None and time.monotonic() > deadline:
+            worst = 124
+            for q in live:
                 q.kill()
+            for q in live:
+                q.wait()
+            break
+        time.sleep(0.05)
     return worst

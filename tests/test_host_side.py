@@ -36,6 +36,47 @@ def test_cabi_exports_every_declared_symbol():
     assert b"gfx950" in lib.rimphony_version()
 
 
+def _c_prototypes(hdr):
+    """name -> number of arguments, for every function the header declares"""
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b((?:rimphony|pkgw_bessel)_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def test_rust_sys_crate_matches_header():
+    """rimphony-hip-sys/ (the Rust -sys source, shipped unbuilt -- the image has no Rust toolchain): every
+    function of its extern block is declared in include/rimphony_hip.h with the same number of arguments, the constants
+    carry the header's values, and the crate has the three files a `links = "rimphony_hip"` crate needs."""
+    crate = os.path.join(ROOT, "rimphony-hip-sys")
+    for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs")):
+        assert os.path.exists(os.path.join(crate, f)), f
+    assert 'links = "rimphony_hip"' in open(os.path.join(crate, "Cargo.toml")).read()
+    assert "rustc-link-lib=dylib=rimphony_hip" in open(os.path.join(crate, "build.rs")).read()
+    hdr = open(os.path.join(ROOT, "include", "rimphony_hip.h")).read()
+    protos = _c_prototypes(hdr)
+    rs = open(os.path.join(crate, "src", "lib.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    fns = re.findall(r"pub fn ([a-z0-9_]+)\s*\(([^)]*)\)", block, flags=re.S)
+    assert len(fns) >= 20
+    for name, args in fns:
+        assert name in protos, "not in the header: " + name
+        nargs = len([a for a in args.split(",") if a.strip()])
+        assert nargs == protos[name], (name, nargs, protos[name])
+    for must in ("rimphony_batch_compute", "rimphony_batch_compute_ex", "rimphony_batch_compute_multi",
+                 "rimphony_ctx_create", "rimphony_ctx_destroy", "pkgw_bessel_j", "pkgw_bessel_dj"):
+        assert must in dict(fns)
+    for cname, val in re.findall(r"pub const (RIMPHONY_[A-Z0-9_]+): [a-z_0-9]+ = ([^;]+);", rs):
+        m = re.search(r"#define\s+%s\s+(.+?)(?:/\*|\n)" % cname, hdr) or re.search(r"\b%s = (-?\d+)" % cname, hdr)
+        assert m, cname
+        cval = m.group(1).strip().replace("u", "").strip("()")
+        assert eval(cval) == eval(val.strip()), (cname, cval, val)
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
@@ -251,6 +292,22 @@ sys.exit(int(sys.argv[1]) if rank == 1 else 0)
     assert "SUM 3.0 2 127.0.0.1" in r.stdout
     r = subprocess.run([sys.executable, "-c", code, "3"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 3
+
+
+def test_spawn_ranks_ends_the_others_when_a_late_rank_dies(tmp_path):
+    """A rank other than 0 dying early must end the run at once (the others would sit in a collective until its own
+    timeout), and `timeout` is one deadline for the whole run."""
+    import time
+    from rimphony_amd import launch
+    script = tmp_path / "d.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(120)\n")
+    t0 = time.time()
+    assert launch.spawn_ranks(2, [str(script)]) == 7
+    assert time.time() - t0 < 20
+    script.write_text("import time\ntime.sleep(120)\n")
+    t0 = time.time()
+    assert launch.spawn_ranks(2, [str(script)], timeout=2) == 124
+    assert time.time() - t0 < 20
 
 
 def test_bench_parent_never_touches_the_gpu():

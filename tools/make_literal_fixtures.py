@@ -6,7 +6,13 @@ DETERMINISTIC flavour; against this one it shows the distribution BASELINE.json'
 asks about (rounding-level differences amplified by the reference's noise-driven control flow).
 
 Writes tests/golden/literal_<config>.npz: start, n, mask, out [n][8] (NaN where not selected or failed).
-CPU only; run in the build container:  python tools/make_literal_fixtures.py [threads]"""
+CPU only; run in the build container:  python tools/make_literal_fixtures.py [threads] [config ...]
+
+--controls (round 3): instead of `out`, ADD two more tables to each file -- the noise floor of the reference's own
+arithmetic.  out_rev: the literal flavour with the GK31 terms added in the opposite order (oracle `make controls`,
+liboracle_libm_rev.so); out_fma: the literal flavour compiled with -ffp-contract=fast (liboracle_libm_fma.so).  Both are
+equally legitimate evaluations of the reference's formulas; the distance literal <-> control is what "agreement with
+the Rust/GSL binary" can mean at best, and bench.py prints it next to the HIP <-> literal distance (`parity.control`)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,8 +22,29 @@ from rimphony_amd import workload
 
 CASES = [("cfg2_powerlaw_jI_aI", 0, 8192), ("cfg2_powerlaw_8", 1000000, 2048), ("cfg3_thermal_8", 0, 2048),
          ("cfg4_pitchypl_8", 0, 2048), ("cfg5_pitchykappa_8", 0, 2048)]
-threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-only = sys.argv[2:] or None
+argv = [a for a in sys.argv[1:] if a != "--controls"]
+controls = "--controls" in sys.argv
+threads = int(argv[0]) if argv else 8
+only = argv[1:] or None
+if controls:
+    import ctypes, subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "controls"], check=True, stdout=subprocess.DEVNULL)
+    for cfg, start, n in CASES:
+        if only and cfg not in only:
+            continue
+        path = os.path.join(ROOT, "tests", "golden", "literal_%s.npz" % cfg)
+        z = dict(np.load(path))
+        kind, mask, s, th, params = workload.make_batch(cfg, n, start=start)
+        for key, lib in (("out_rev", "liboracle_libm_rev.so"), ("out_fma", "liboracle_libm_fma.so")):
+            L = ctypes.CDLL(os.path.join(ROOT, "oracle", lib))
+            L.rimo_batch.restype = ctypes.c_int
+            L.rimo_batch.argtypes = oracle_bind.load("libm").rimo_batch.argtypes
+            L.rimo_build_flavour.restype = ctypes.c_char_p
+            t0 = time.time()
+            z[key] = oracle_bind.batch(L, kind, s, th, params, mask, nthreads=threads)
+            print("%s %s (%s): %d rows in %.0f s" % (cfg, key, L.rimo_build_flavour().decode(), n, time.time() - t0), flush=True)
+        np.savez_compressed(path, **z)
+    sys.exit(0)
 L = oracle_bind.load("libm")
 assert b"libm" in L.rimo_build_flavour() or "libm" in str(L.rimo_build_flavour())
 for cfg, start, n in CASES:
