@@ -90,9 +90,11 @@ int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unkno
  * integrand -- the exponential of a reduced argument, the logarithm of a mantissa, the Debye cube root -- in single
  * precision on the hardware transcendental unit, with every difference, every product with the harmonic number and
  * every quadrature sum in fp64; it applies to the six Symphony slots (the Faraday pair is always fp64) and carries
- * no parity claim: ~1e-8 median, ~1e-6 p99 relative difference from F64, and a noisier integrand for the adaptive
- * quadrature (DESIGN.md section 5 has the measured distributions and where it is slower than F64).  Any other value:
- * RIMPHONY_ENOTSUP. */
+ * no parity claim: ~1e-8 median, ~1e-6 p99 relative difference from F64, 0.90 (power law) / 0.96 (thermal) of the fp64
+ * kernel time.  It is offered for RIMPHONY_POWER_LAW and RIMPHONY_THERMAL_JUETTNER only: for the
+ * anisotropic distributions (PITCHY_PL, PITCHY_KAPPA -- the one BASELINE configs[4] names) it was measured 1.53 x SLOWER
+ * than fp64 with 1.9 % new NaNs, because its non-smooth 1e-7 noise trips GSL's round-off detectors on integrals that
+ * cancel; those kinds return RIMPHONY_ENOTSUP, as does any other `precision` value. */
 #define RIMPHONY_PRECISION_F64            0
 #define RIMPHONY_PRECISION_F32_INTEGRAND  1
 
@@ -131,6 +133,16 @@ typedef struct {
     uint64_t faraday_inner_qags;
 } rimphony_work;
 int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
+
+/* The tail of the most recent batch call (device-side, read back synchronously).  Per-task cost has a heavy tail and the
+ * reference's chunk marching is sequential: the task with the longest CHAIN of batches (each waits for its slowest
+ * gamma-integral / inner integral) bounds how early a launch can end, whatever the cooperative tail spreads out.
+ *   out[0], out[1]   Symphony: batches of the heaviest coefficient, and its row
+ *   out[2], out[3]   Faraday: the same
+ *   out[4]           Symphony group kernel: passes the coefficients would have executed one by one (out[4] / passes of
+ *                    rimphony_last_work = how many coefficients an executed pass served on average)
+ *   out[5]           ... rule sums filed ahead of a coefficient's own pick (the stash of symphony_group.h) */
+int rimphony_last_tail(rimphony_ctx *ctx, uint64_t out[6]);
 
 /* Duration of the most recent Symphony kernel launch of this context, measured
  * with HIP events recorded on the stream the kernel was launched on (waits for

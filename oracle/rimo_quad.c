@@ -39,7 +39,7 @@ static double rescale_error(double err, const double result_abs, const double re
     return err;
 }
 
-#ifndef RIMO_LIBM
+#if !defined(RIMO_LIBM) && !defined(RIMO_GK_PER_NODE)
 /* The deterministic flavour forms QUADPACK's own terms -- w (f1 + f2) per symmetric pair of nodes, the centre alone --
  * and adds the 16 terms in the order of the wavefront kernel: pair k of the rule (abscissa xgk[k], k = 0..14; slot 15
  * is the centre) sits on lanes 2k and 2k + 1 of a half-wave, the first butterfly step (xor 1) is the pair sum
@@ -105,6 +105,24 @@ void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
             const int jtwm1 = 2 * j;
             result_asc += GK_WK[jtwm1] * (m_fabs(fv[jtwm1] - mean) + m_fabs(fv[30 - jtwm1] - mean));
         }
+    }
+#elif defined(RIMO_GK_PER_NODE)
+    {
+        /* The deterministic flavour as it was until round 2 (tools/nan_rootcause.py only): one product w f per NODE,
+         * 32 terms in the butterfly order.  With subnormal samples every product rounds to whole quanta of 2^-1074, so
+         * the products of small samples vanish where qk.c's pair terms w (f1 + f2) survive: the cause of the one-sided
+         * NaNs of round 2. */
+        double t[32];
+#define TREE32(v) do { for (int w_ = 1; w_ < 32; w_ <<= 1) for (int i_ = 0; i_ < 32; i_ += 2 * w_) v[i_] = v[i_] + v[i_ + w_]; } while (0)
+        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * fv[j];
+        TREE32(t); result_kronrod = t[0];
+        for (int j = 0; j < 32; j++) t[j] = GK_WG[j] * fv[j];
+        TREE32(t); result_gauss = t[0];
+        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * m_fabs(fv[j]);
+        TREE32(t); result_abs = t[0];
+        mean = result_kronrod * 0.5;
+        for (int j = 0; j < 32; j++) t[j] = GK_WK[j] * m_fabs(fv[j] - mean);
+        TREE32(t); result_asc = t[0];
     }
 #else
     {
@@ -496,6 +514,8 @@ const char *rimo_build_flavour(void)
     return "libm+gsl-order+contracted";
 #elif defined(RIMO_LIBM)
     return "libm+gsl-order";
+#elif defined(RIMO_GK_PER_NODE)
+    return "detmath+tree-order, per-node products (round 2)";
 #else
     return "detmath+tree-order";
 #endif

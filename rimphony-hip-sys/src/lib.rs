@@ -86,6 +86,7 @@ extern "C" {
     pub fn rimphony_version() -> *const c_char;
 
     pub fn rimphony_last_work(ctx: *mut rimphony_ctx, out: *mut rimphony_work) -> c_int;
+    pub fn rimphony_last_tail(ctx: *mut rimphony_ctx, out: *mut u64) -> c_int;
     pub fn rimphony_last_symphony_ms(ctx: *mut rimphony_ctx, ms: *mut c_float) -> c_int;
     pub fn rimphony_last_faraday_ms(ctx: *mut rimphony_ctx, ms: *mut c_float) -> c_int;
 

@@ -41,6 +41,17 @@ def hip_sources():
     return srcs
 
 
+def source_id():
+    """16 hex digits identifying the kernel sources of this tree (csrc/*.h, *.hip, the C-ABI header): profiles record
+    it so that bench.py only quotes a PMC figure for the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in hip_sources():
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def find_hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

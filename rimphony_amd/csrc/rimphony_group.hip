@@ -156,6 +156,8 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                         const int sl = group_slot(own_slots, m);
                         a.out[own_i * 8 + sl] = val;
                         if (a.status) a.status[own_i * 8 + sl] = st;
+                        // the heaviest member of the launch: its sequential chain of batches bounds the launch's tail
+                        atomicMax(a.queue + 14, ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));
                     }
                 }
                 __syncthreads();

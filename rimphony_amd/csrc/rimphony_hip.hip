@@ -307,7 +307,9 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (finished) {
                     int st = 0;
                     const double val = P::result(cx, T, st);
-                    COOP_DIAG(if (lane == 0) atomicMax(a.queue + 15, ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));)
+                    // the heaviest task of the launch: its sequential chain of batches bounds the launch's tail
+                    // (queue word 15 of the kernel's block: (batches << 24) | point index; rimphony_last_tail)
+                    if (lane == 0) atomicMax(a.queue + (P::QUEUE ? 15 : 14), ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
                         if (a.status) a.status[own_i * 8 + own_slot] = st;
@@ -1227,6 +1229,12 @@ extern "C" int rimphony_batch_compute_device_ex(rimphony_ctx *c, int kind, size_
 {
     if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
     if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
+    // The fp32-integrand variant is not offered for the anisotropic distributions: measured on pitchy kappa -- the
+    // distribution BASELINE configs[4] names -- its 1e-7 non-smooth noise sits above GSL's round-off detectors on integrals
+    // that cancel, the quadratures bisect 32 % more and give up: 1.53 x SLOWER than fp64 with 1.9 % new NaNs
+    // (profiles/r2_f32_integrand_variant.txt).  A precision that is slower and lossier is not a mode, it is a trap.
+    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
+        return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
     if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
@@ -1317,12 +1325,9 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
     if (a.nslots > 0) {
         if (precision == RIMPHONY_PRECISION_F32_INTEGRAND) {
             // the six Symphony coefficients with the fp32-core integrand (detmath.h); the Faraday pair below stays fp64
-            switch (kind) {
-            case 0: rc = launch_symphony<0, 1>(c, a, st); break;
-            case 1: rc = launch_symphony<1, 1>(c, a, st); break;
-            case 2: rc = launch_symphony<2, 1>(c, a, st); break;
-            default: rc = launch_symphony<3, 1>(c, a, st); break;
-            }
+            // (kinds 2 and 3 were refused at the entry: RIMPHONY_ENOTSUP)
+            if (kind == 0) rc = launch_symphony<0, 1>(c, a, st);
+            else rc = launch_symphony<1, 1>(c, a, st);
         } else if (!c->sym_solo) {
             // the coefficients of a point that share their samples advance in lock-step on one wave
             rc = launch_group(c, kind, a, coeff_mask, st);
@@ -1422,12 +1427,27 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
     return RIMPHONY_OK;
 }
 
+extern "C" int rimphony_last_tail(rimphony_ctx *c, uint64_t out[6])
+{
+    if (!c || !out) return RIMPHONY_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[16];
+    if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));
+    HIP_TRY(hipMemcpy(h, c->d_queue, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[14] >> 24; out[1] = h[14] & 0xffffffull;
+    out[2] = h[15] >> 24; out[3] = h[15] & 0xffffffull;
+    out[4] = h[8]; out[5] = h[9];
+    return RIMPHONY_OK;
+}
+
 extern "C" int rimphony_batch_compute_ex(rimphony_ctx *c, int kind, size_t n,
                                          const double *s, const double *theta, const double *const *params,
                                          uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work)
 {
     if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
     if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
+    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
+        return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];
@@ -1504,6 +1524,8 @@ extern "C" int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx
     if (!ctxs || n_ctx < 1 || n_ctx > 64 || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
     for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return RIMPHONY_EINVAL;
     if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
+    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
+        return RIMPHONY_ENOTSUP;
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta || !out) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];

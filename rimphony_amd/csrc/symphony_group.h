@@ -108,7 +108,83 @@ __device__ __forceinline__ int stash_find(const GroupMember *M, int idx, int lan
 }
 
 // ---- the adaptive quadratures of up to RIM_GROUP members over one or two intervals, in lock-step ---------------
-//
+
+// qag.c's loop body for member M after the two children of its picked entry `imax` = [a_i, b_i] have been evaluated:
+// area / error of child 1 and 2 in lane 0's view (every lane executes, decisions are lane 0's), ne_both = "resasc !=
+// error for both children", r_own / e_own = the sums of THIS lane's child (lanes 0 and 32 file their own child).
+// Returns true when the member's integral is finished (result and status filed in M->res[cur] / M->qst[cur]).
+__device__ __forceinline__ bool group_book(GroupMember *M, const IStore &st, const GKLane &g, int cur, int imax,
+                                           double a_i, double b_i, double area1, double error1, double area2, double error2,
+                                           bool ne_both, double r_own, double e_own, double epsrel, int limit)
+{
+    const int lane = g.lane;
+    int iteration = uni(M->iteration), size = uni(M->size), rt1 = uni(M->rt1), rt2 = uni(M->rt2);
+    const IEntry en = ist_entry(st, imax);
+    const double r_i = en.r, e_i = en.e;
+    const double mid = 0.5 * (a_i + b_i);
+    const double area12 = area1 + area2;
+    const double error12 = error1 + error2;
+    const double errsum = M->errsum + (error12 - e_i);
+    const double area = M->area + (area12 - r_i);
+    if (ne_both) {
+        const double delta = r_i - area12;
+        if (lane0_and(rim_fabs(delta) <= 1.0e-5 * rim_fabs(area12), error12 >= 0.99 * e_i)) rt1++;
+        if (iteration >= 10 && lane0(error12 > e_i)) rt2++;
+    }
+    const double tolerance = epsrel * rim_fabs(area);          // = rim_max(0, x) for x >= 0 or NaN: epsabs is 0 on this path
+    const bool more = lane0(errsum > tolerance);
+    int error_type = 0;
+    if (more) {
+        if (rt1 >= 6 || rt2 >= 20) error_type = 2;
+        const double tmp = (1 + 100 * RIM_DBL_EPSILON) * (rim_fabs(mid) + 1000 * RIM_DBL_MIN);
+        if (lane0_and(rim_fabs(a_i) <= tmp, rim_fabs(b_i) <= tmp)) error_type = 3;
+    }
+    // update(): the child with the larger error keeps the parent's slot; lanes 0 and 32 file their own child
+    const bool c2gt = lane0(error2 > error1);
+    const bool overflow = size >= istore_capacity(st);
+    wv_sync();               // every lane has read the parent's entry and the member's sums
+    if (!overflow) {
+        if ((lane & 31) == 0) {
+            const bool keep = (g.half != 0) == c2gt;
+            const int slot = keep ? imax : size;
+            const int stamp = 2 * iteration + (keep ? 0 : 1);
+            const double la = g.half ? mid : a_i, lb = g.half ? b_i : mid;
+            if (slot < st.cap) {
+                st.a[slot] = la; st.b[slot] = lb; st.r[slot] = r_own; st.e[slot] = e_own;
+                st.stamp[slot] = stamp;
+            } else {         // beyond the LDS part: the wave's spill region in global memory
+                const int j = slot - st.cap;
+                st.g[j] = la; st.g[st.gcap + j] = lb; st.g[2 * st.gcap + j] = r_own; st.g[3 * st.gcap + j] = e_own;
+                ((int *) (st.g + 4 * st.gcap))[j] = stamp;
+            }
+        }
+        size++;
+    }
+    iteration++;
+    const bool finished = !(!overflow && iteration < limit && !error_type && more);
+    if (lane == 0) {
+        M->area = area; M->errsum = errsum;
+        M->iteration = iteration; M->size = size; M->rt1 = rt1; M->rt2 = rt2;
+        M->samples += 62u;
+    }
+    if (finished) {
+        wv_sync();
+        double sum = 0;
+        if (size <= st.cap) { for (int k = 0; k < size; k++) sum += st.r[k]; }
+        else { for (int k = 0; k < size; k++) sum += ist_r(st, k); }
+        int status;
+        if (lane0(errsum <= tolerance)) status = QAG_SUCCESS;      // (not "!more": a NaN error sum is a failure)
+        else if (overflow) status = QAG_ESTORE;
+        else if (error_type == 2) status = QAG_EROUND;
+        else if (error_type == 3) status = QAG_ESING;
+        else if (iteration == limit) status = QAG_EMAXITER;
+        else status = QAG_EFAILED;
+        if (lane == 0) { M->res[cur] = sum; M->qst[cur] = status; }
+        RIM_HIT(22);
+    }
+    return finished;
+}
+
 // Integral A on [a0, b0] for the members of maskA, integral B on [a1, b1] for those of maskB (maskB == 0: none); as in
 // wave_qag_pair the two share their first rule application (A on lanes 0..30, B on 32..62), then A's members run to
 // the end, then B's.  The integrand is a functor with two steps:
@@ -116,7 +192,9 @@ __device__ __forceinline__ int stash_find(const GroupMember *M, int idx, int lan
 //                                          x and `active`; `second` selects integral B's order data; `members` says whose
 //                                          terms will be asked for)
 //   f.member(m, active) -> double          member m's integrand value at the lane's sample (0 on inactive lanes)
-// Each member's arithmetic is that of wave_qag_pair / qag.c: results in gp->mem[m].res[] / .qst[].
+// Each member's arithmetic is that of wave_qag_pair / qag.c: results in gp->mem[m].res[] / .qst[].  One loop, one
+// site of the integrand: a turn of the loop is the joint first rule application (cur < 0), a pass over the two
+// children of an interval, or the booking of members whose pick was on file in their stash.
 template <class F>
 __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *inner_lds, double *inner_spill,
                                                double a0, double b0, double a1, double b1, unsigned maskA, unsigned maskB,
@@ -125,84 +203,35 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
     const int lane = g.lane;
     const bool have1 = maskB != 0;
     unsigned n_pass = 0, n_member_pass = 0, n_samp_all = 0, n_qags = 0, n_filed = 0, n_used = 0;
+    int cur = -1;                       // -1: the joint first rule application; then integral 0 (A) and 1 (B)
+    unsigned active = 0, need_pick = 0;
+    unsigned stashed = 0;               // bit m: member m's stash may hold entries (else no look-up is needed)
 
-    // ---------------- the joint first rule application ----------------
-    {
-        const bool second = g.half != 0 && have1;
-        const double la = second ? a1 : a0, lb = second ? b1 : b0;
-        const double hl = 0.5 * (lb - la);
-        const double x = 0.5 * (la + lb) + hl * gk_t(g);
-        const unsigned both = maskA | maskB;
-        const bool act_any = g.node && (g.half == 0 ? maskA != 0 : have1);
-        RIM_HIT(0); RIM_HIT(1);
-        f.shared(x, act_any, second, both);
-        wv_sync();                              // nobody still reads the previous evaluation's member records
-        for (unsigned rem = both; rem; rem &= rem - 1) {
-            const int m = __builtin_ctz(rem);
-            const bool inA = ((maskA >> m) & 1u) != 0, inB = ((maskB >> m) & 1u) != 0;
-            const double fv = f.member(m, g.node && (g.half == 0 ? inA : inB));
-            const GKRes r = wave_gk31(fv, hl, g);
-            GroupMember *const M = gp->mem + m;
-            if ((lane == 0 && inA) || (lane == 32 && inB)) {
-                double *fb = M->fb[g.half];
-                fb[0] = r.result; fb[1] = r.abserr; fb[2] = r.resabs; fb[3] = r.resasc;
-            }
-            if (lane == 0) M->samples = (inA ? 31u : 0u) + (inB ? 31u : 0u);
-            n_samp_all += (inA ? 31u : 0u) + (inB ? 31u : 0u);
-            n_member_pass += 1;
-            n_qags += (inA ? 1u : 0u) + (inB ? 1u : 0u);
-        }
-        n_pass += 1;
-    }
+    wv_sync();                          // nobody still reads the previous evaluation's member records
+    for (;;) {
+        unsigned serve = 0;             // members whose rule sums this turn's pass produces
+        unsigned booknow = 0;           // ... of them, those that picked the pass's interval: booked from the registers
+        unsigned from_stash = 0;        // members whose pick is on file: booked without a pass
+        int idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0;      // entry of the pass's interval in each served member's list
+        double a_i = 0., b_i = 0.;      // the pass's interval (uniform)
+        double la = 0., lb = 0.;        // per lane: the interval this lane's sample belongs to
+        bool active_lane = false, second = false;
 
-    // ---------------- integral A's members to the end, then integral B's ----------------
-    for (int cur = 0; cur < (have1 ? 2 : 1); cur++) {
-        const unsigned mask = cur ? maskB : maskA;
-        const double fa = cur ? a1 : a0, fbnd = cur ? b1 : b0;
-        unsigned active = 0;
-        wv_sync();                              // the first-rule sums are visible to every lane
-        for (unsigned rem = mask; rem; rem &= rem - 1) {
-            // qag_after_first on the member's first-rule sums
-            const int m = __builtin_ctz(rem);
-            GroupMember *const M = gp->mem + m;
-            const double f_res = M->fb[cur][0], f_err = M->fb[cur][1], f_abs = M->fb[cur][2], f_asc = M->fb[cur][3];
-            int status = QAG_SUCCESS;
-            bool finished = true;
-            if (epsrel < 50 * RIM_DBL_EPSILON || epsrel < 0.5e-28) {
-                if (lane == 0) { M->res[cur] = 0.; M->qst[cur] = QAG_EBADTOL; }
-                continue;
-            }
-            const double tolerance = epsrel * rim_fabs(f_res);          // = rim_max(0, x): epsabs is 0 on this path
-            const double round_off = 50 * RIM_DBL_EPSILON * f_abs;
-            if (lane0_and(f_err <= round_off, f_err > tolerance)) status = QAG_EROUND;
-            else if (lane0_and(f_err <= tolerance, f_err != f_asc) || lane0(f_err == 0.0)) status = QAG_SUCCESS;
-            else if (limit == 1) status = QAG_EMAXITER;
-            else finished = false;
-            if (finished) {
-                if (lane == 0) { M->res[cur] = f_res; M->qst[cur] = status; }
-            } else {
-                const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
-                if (lane == 0) {
-                    st.a[0] = fa; st.b[0] = fbnd; st.r[0] = f_res; st.e[0] = f_err; st.stamp[0] = 0;
-                    M->area = f_res; M->errsum = f_err;
-                    M->iteration = 1; M->size = 1; M->rt1 = 0; M->rt2 = 0; M->imax = 0; M->snext = 0;
-                }
-                if (lane < RIM_STASH) M->sk[lane] = -1;
-                active |= 1u << m;
-            }
-        }
-        unsigned need_pick = active;
-
-        while (active) {
-            // ---- every member whose list changed picks its next interval; a pick whose children's sums are in the
-            //      member's stash is booked at once (no pass), and the member picks again ----
-            unsigned book = 0;                  // members to be booked from their stash now
-            wv_sync();                          // list entries and member records written above are visible
+        if (cur < 0) {
+            second = g.half != 0 && have1;
+            la = second ? a1 : a0; lb = second ? b1 : b0;
+            serve = maskA | maskB;
+            active_lane = g.node && (g.half == 0 || have1);
+            RIM_HIT(1);
+        } else {
+            // every member whose list changed picks its next interval; a pick whose children's sums are on file in the
+            // member's stash is booked at once
+            wv_sync();                  // list entries and member records written in the last turn are visible
             for (unsigned rem = need_pick; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
                 GroupMember *const M = gp->mem + m;
                 const int size = uni(M->size);
-                int imax = 0;                   // qpsrt: slot 0 while the list has <= 2 entries
+                int imax = 0;           // qpsrt: slot 0 while the list has <= 2 entries
                 if (size > 2) {
                     const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
                     RIM_PROF_T(t_pick);
@@ -210,29 +239,25 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     RIM_PROF_ADD(13, t_pick);
                 }
                 if (lane == 0) M->imax = imax;
-                if (stash_find(M, imax, lane) >= 0) book |= 1u << m;
+                if (((stashed >> m) & 1u) && stash_find(M, imax, lane) >= 0) from_stash |= 1u << m;
             }
+            if (need_pick) wv_sync();
             need_pick = 0;
-            wv_sync();
-
-            double la = 0., lb = 0., hl = 0.;   // per lane: this lane's child of the pass's interval
-            if (!book) {
-                // ---- a pass: the interval of the first active member ----
+            if (!from_stash) {
+                // a pass: the interval of the first active member; it serves the members that picked this interval and
+                // the members that hold it as an entry of their list (their sums go to the stash)
                 const int m0 = __builtin_ctz(active);
-                double a_i, b_i;
                 {
                     const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m0);
                     const int imax = uni(gp->mem[m0].imax);
                     if (imax < st.cap) { a_i = st.a[imax]; b_i = st.b[imax]; }
                     else { a_i = st.g[imax - st.cap]; b_i = st.g[st.gcap + (imax - st.cap)]; }
+                    a_i = uni(a_i); b_i = uni(b_i);
+                    idx0 = idx1 = idx2 = idx3 = imax;
                 }
-                a_i = uni(a_i); b_i = uni(b_i);
                 const unsigned long long abits = rim_bits(a_i), bbits = rim_bits(b_i);
-                // who gets rule sums from this pass: the members that picked this interval (they are booked right
-                // after it) and the members that hold it as an entry of their list (stashed)
-                unsigned serve = 0;
-                int idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0;      // entry index of the interval in each served member's list
-                for (unsigned rem = active; rem; rem &= rem - 1) {
+                serve = booknow = 1u << m0;
+                for (unsigned rem = active & ~serve; rem; rem &= rem - 1) {
                     const int m = __builtin_ctz(rem);
                     GroupMember *const M = gp->mem + m;
                     const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
@@ -241,13 +266,13 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     if (imax < st.cap) { am = st.a[imax]; bm = st.b[imax]; }
                     else { am = st.g[imax - st.cap]; bm = st.g[st.gcap + (imax - st.cap)]; }
                     int idx = -1;
-                    if (rim_bits(uni(am)) == abits && rim_bits(uni(bm)) == bbits) { idx = imax; book |= 1u << m; }
+                    if (rim_bits(uni(am)) == abits && rim_bits(uni(bm)) == bbits) { idx = imax; booknow |= 1u << m; }
                     else if (size <= 64 && size <= st.cap) {
-                        const unsigned long long hit = wv_ballot(lane < size && rim_bits(st.a[lane < size ? lane : 0]) == abits &&
-                                                                 rim_bits(st.b[lane < size ? lane : 0]) == bbits);
+                        const int l = lane < size ? lane : 0;
+                        const unsigned long long hit = wv_ballot(lane < size && rim_bits(st.a[l]) == abits && rim_bits(st.b[l]) == bbits);
                         if (hit) {
                             idx = __builtin_ffsll((long long) hit) - 1;
-                            if (stash_find(M, idx, lane) >= 0) idx = -1;       // already on file
+                            if (((stashed >> m) & 1u) && stash_find(M, idx, lane) >= 0) idx = -1;       // already on file
                         }
                     }
                     if (idx >= 0) { serve |= 1u << m; put4(m, idx, idx0, idx1, idx2, idx3); }
@@ -255,115 +280,139 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                 const double mid = 0.5 * (a_i + b_i);
                 la = g.half ? mid : a_i;
                 lb = g.half ? b_i : mid;
-                hl = 0.5 * (lb - la);
-                const double x = 0.5 * (la + lb) + hl * gk_t(g);
-                RIM_HIT(0);
-                RIM_PROF_T(t_int);
-                f.shared(x, g.node, cur != 0, serve);
-                RIM_PROF_ADD(1, t_int);
-                n_pass += 1;
-                for (unsigned rem = serve; rem; rem &= rem - 1) {
-                    const int m = __builtin_ctz(rem);
-                    GroupMember *const M = gp->mem + m;
-                    const double fv = f.member(m, g.node);
-                    RIM_PROF_T(t_gk);
-                    const GKRes r = wave_gk31(fv, hl, g);
-                    RIM_PROF_ADD(11, t_gk);
-                    const unsigned long long ne = wv_ballot(r.resasc != r.abserr);
-                    const int idx = sel4(m, idx0, idx1, idx2, idx3);
-                    // file the children's sums in the member's stash (a free place, else the next one in turn)
-                    const unsigned long long freep = wv_ballot(lane < RIM_STASH && M->sk[lane & (RIM_STASH - 1)] < 0);
-                    const int pos = freep ? __builtin_ffsll((long long) freep) - 1 : uni(M->snext);
-                    wv_sync();
-                    if (lane == 0) {
-                        M->sk[pos] = idx;
-                        M->sf[pos] = (int) (ne & 1ull) | (int) (((ne >> 32) & 1ull) << 1);
-                        M->sr1[pos] = r.result; M->se1[pos] = r.abserr;
-                        if (!freep) M->snext = (pos + 1) & (RIM_STASH - 1);
-                    }
-                    if (lane == 32) { M->sr2[pos] = r.result; M->se2[pos] = r.abserr; }
-                    if (!((book >> m) & 1u)) n_filed += 1;
-                }
-                wv_sync();
+                active_lane = g.node;
+                second = cur != 0;
             }
+        }
 
-            // ---- book the members whose pick has its children's sums on file (qag.c's loop body) ----
-            for (unsigned rem = book; rem; rem &= rem - 1) {
+        if (serve) {
+            // ---- one pass: the integrand's shared part once, then every served member's terms and rule sums ----
+            const double hl = 0.5 * (lb - la);
+            const double x = 0.5 * (la + lb) + hl * gk_t(g);
+            RIM_HIT(0);
+            RIM_PROF_T(t_int);
+            f.shared(x, active_lane, second, serve);
+            RIM_PROF_ADD(1, t_int);
+            n_pass += 1;
+#if defined(RIM_WAVE_EMU)
+            if (lane == 0) { extern unsigned long long g_emu_hist[64]; g_emu_hist[(cur < 0 ? 0 : 8) + __builtin_popcount(cur < 0 ? serve : booknow)]++;
+                             if (cur >= 0) g_emu_hist[16 + __builtin_popcount(active)]++; }
+#endif
+            for (unsigned rem = serve; rem; rem &= rem - 1) {
+                const int m = __builtin_ctz(rem);
+                GroupMember *const M = gp->mem + m;
+                const bool inA = ((maskA >> m) & 1u) != 0, inB = ((maskB >> m) & 1u) != 0;
+                const bool act_m = cur < 0 ? (g.node && (g.half == 0 ? inA : inB)) : g.node;
+                const double fv = f.member(m, act_m);
+                RIM_PROF_T(t_gk);
+                const GKRes r = wave_gk31(fv, hl, g);
+                RIM_PROF_ADD(11, t_gk);
+                if (cur < 0) {
+                    // the joint first application: file the first-rule sums of the member's integral(s)
+                    if ((lane == 0 && inA) || (lane == 32 && inB)) {
+                        double *fb = M->fb[g.half];
+                        fb[0] = r.result; fb[1] = r.abserr; fb[2] = r.resabs; fb[3] = r.resasc;
+                    }
+                    const unsigned ns = (inA ? 31u : 0u) + (inB ? 31u : 0u);
+                    if (lane == 0) M->samples = ns;
+                    n_samp_all += ns;
+                    n_member_pass += 1;
+                    n_qags += (inA ? 1u : 0u) + (inB ? 1u : 0u);
+                } else {
+                    const unsigned long long ne = wv_ballot(r.resasc != r.abserr);
+                    if ((booknow >> m) & 1u) {
+                        RIM_PROF_T(t_ab);
+                        const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
+                        const bool fin = group_book(M, st, g, cur, sel4(m, idx0, idx1, idx2, idx3), a_i, b_i,
+                                                    r.result, r.abserr, readlane_d(r.result, 32), readlane_d(r.abserr, 32),
+                                                    (ne & 1ull) && ((ne >> 32) & 1ull), r.result, r.abserr, epsrel, limit);
+                        n_samp_all += 62u;
+                        n_member_pass += 1;
+                        if (fin) active &= ~(1u << m); else need_pick |= 1u << m;
+                        RIM_PROF_ADD(12, t_ab);
+                    } else {
+                        // file the children's sums in the member's stash (a free place, else the next one in turn)
+                        const int idx = sel4(m, idx0, idx1, idx2, idx3);
+                        const unsigned long long freep = wv_ballot(lane < RIM_STASH && M->sk[lane & (RIM_STASH - 1)] < 0);
+                        const int pos = freep ? __builtin_ffsll((long long) freep) - 1 : uni(M->snext);
+                        wv_sync();
+                        if (lane == 0) {
+                            M->sk[pos] = idx;
+                            M->sf[pos] = (int) (ne & 1ull) | (int) (((ne >> 32) & 1ull) << 1);
+                            M->sr1[pos] = r.result; M->se1[pos] = r.abserr;
+                            if (!freep) M->snext = (pos + 1) & (RIM_STASH - 1);
+                        }
+                        if (lane == 32) { M->sr2[pos] = r.result; M->se2[pos] = r.abserr; }
+                        stashed |= 1u << m;
+                        n_filed += 1;
+                    }
+                }
+            }
+        }
+
+        if (from_stash) {
+            // ---- members whose pick has its children's sums on file: qag.c's loop body without a pass ----
+            for (unsigned rem = from_stash; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
                 GroupMember *const M = gp->mem + m;
                 const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
-                RIM_PROF_T(t_ab);
-                int iteration = uni(M->iteration), size = uni(M->size), rt1 = uni(M->rt1), rt2 = uni(M->rt2);
                 const int imax = uni(M->imax);
                 const int pos = stash_find(M, imax, lane);
                 const double area1 = M->sr1[pos], error1 = M->se1[pos], area2 = M->sr2[pos], error2 = M->se2[pos];
                 const int sfl = uni(M->sf[pos]);
                 const IEntry en = ist_entry(st, imax);
-                const double a_i = en.a, b_i = en.b, r_i = en.r, e_i = en.e;
-                const double mid = 0.5 * (a_i + b_i);
-                const double area12 = area1 + area2;
-                const double error12 = error1 + error2;
-                const double errsum = M->errsum + (error12 - e_i);
-                const double area = M->area + (area12 - r_i);
-                if (sfl == 3) {                 // resasc != error for both children
-                    const double delta = r_i - area12;
-                    if (lane0_and(rim_fabs(delta) <= 1.0e-5 * rim_fabs(area12), error12 >= 0.99 * e_i)) rt1++;
-                    if (iteration >= 10 && lane0(error12 > e_i)) rt2++;
-                }
-                const double tolerance = epsrel * rim_fabs(area);          // = rim_max(0, x) for x >= 0 or NaN
-                const bool more = lane0(errsum > tolerance);
-                int error_type = 0;
-                if (more) {
-                    if (rt1 >= 6 || rt2 >= 20) error_type = 2;
-                    const double tmp = (1 + 100 * RIM_DBL_EPSILON) * (rim_fabs(mid) + 1000 * RIM_DBL_MIN);
-                    if (lane0_and(rim_fabs(a_i) <= tmp, rim_fabs(b_i) <= tmp)) error_type = 3;
-                }
-                // update(): the child with the larger error keeps the parent's slot, the other one is appended
-                const bool c2gt = lane0(error2 > error1);
-                const bool overflow = size >= istore_capacity(st);
-                wv_sync();               // every lane has read the parent's entry, the stash and the member's sums
-                if (!overflow) {
-                    if (lane == 0) {
-                        const int s1 = c2gt ? size : imax, s2 = c2gt ? imax : size;      // slots of child 1 and child 2
-                        ist_set_a(st, s1, a_i); ist_set_b(st, s1, mid); ist_set_r(st, s1, area1); ist_set_e(st, s1, error1);
-                        ist_set_stamp(st, s1, 2 * iteration + (c2gt ? 1 : 0));
-                        ist_set_a(st, s2, mid); ist_set_b(st, s2, b_i); ist_set_r(st, s2, area2); ist_set_e(st, s2, error2);
-                        ist_set_stamp(st, s2, 2 * iteration + (c2gt ? 0 : 1));
-                    }
-                    size++;
-                }
-                iteration++;
-                const bool finished = !(!overflow && iteration < limit && !error_type && more);
-                if (lane == 0) {
-                    M->area = area; M->errsum = errsum;
-                    M->iteration = iteration; M->size = size; M->rt1 = rt1; M->rt2 = rt2;
-                    M->samples += 62u;
-                    M->sk[pos] = -1;
-                }
+                wv_sync();
+                if (lane == 0) M->sk[pos] = -1;
+                const bool fin = group_book(M, st, g, cur, imax, uni(en.a), uni(en.b), area1, error1, area2, error2, sfl == 3,
+                                            g.half ? area2 : area1, g.half ? error2 : error1, epsrel, limit);
                 n_samp_all += 62u;
                 n_member_pass += 1;
-                if (finished) {
-                    wv_sync();
-                    double sum = 0;
-                    if (size <= st.cap) { for (int k = 0; k < size; k++) sum += st.r[k]; }
-                    else { for (int k = 0; k < size; k++) sum += ist_r(st, k); }
-                    int status;
-                    if (lane0(errsum <= tolerance)) status = QAG_SUCCESS;      // (not "!more": a NaN error sum is a failure)
-                    else if (overflow) status = QAG_ESTORE;
-                    else if (error_type == 2) status = QAG_EROUND;
-                    else if (error_type == 3) status = QAG_ESING;
-                    else if (iteration == limit) status = QAG_EMAXITER;
-                    else status = QAG_EFAILED;
-                    if (lane == 0) { M->res[cur] = sum; M->qst[cur] = status; }
-                    active &= ~(1u << m);
-                    RIM_HIT(22);
-                } else {
-                    need_pick |= 1u << m;
-                }
-                RIM_PROF_ADD(12, t_ab);
+                n_used += 1;
+                if (fin) active &= ~(1u << m); else need_pick |= 1u << m;
             }
-            n_used += 0;
         }
+
+        // ---- the next integral, once the current one has no unfinished member ----
+        while (cur < 0 || !active) {
+            cur += 1;
+            if (cur > (have1 ? 1 : 0)) break;
+            const unsigned mask = cur ? maskB : maskA;
+            const double fa = cur ? a1 : a0, fbnd = cur ? b1 : b0;
+            wv_sync();                          // the first-rule sums are visible to every lane
+            stashed = 0;
+            for (unsigned rem = mask; rem; rem &= rem - 1) {
+                // qag_after_first on the member's first-rule sums
+                const int m = __builtin_ctz(rem);
+                GroupMember *const M = gp->mem + m;
+                const double f_res = M->fb[cur][0], f_err = M->fb[cur][1], f_abs = M->fb[cur][2], f_asc = M->fb[cur][3];
+                int status = QAG_SUCCESS;
+                bool finished = true;
+                if (epsrel < 50 * RIM_DBL_EPSILON || epsrel < 0.5e-28) {
+                    if (lane == 0) { M->res[cur] = 0.; M->qst[cur] = QAG_EBADTOL; }
+                    continue;
+                }
+                const double tolerance = epsrel * rim_fabs(f_res);          // = rim_max(0, x): epsabs is 0 on this path
+                const double round_off = 50 * RIM_DBL_EPSILON * f_abs;
+                if (lane0_and(f_err <= round_off, f_err > tolerance)) status = QAG_EROUND;
+                else if (lane0_and(f_err <= tolerance, f_err != f_asc) || lane0(f_err == 0.0)) status = QAG_SUCCESS;
+                else if (limit == 1) status = QAG_EMAXITER;
+                else finished = false;
+                if (finished) {
+                    if (lane == 0) { M->res[cur] = f_res; M->qst[cur] = status; }
+                } else {
+                    const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
+                    if (lane == 0) {
+                        st.a[0] = fa; st.b[0] = fbnd; st.r[0] = f_res; st.e[0] = f_err; st.stamp[0] = 0;
+                        M->area = f_res; M->errsum = f_err;
+                        M->iteration = 1; M->size = 1; M->rt1 = 0; M->rt2 = 0; M->imax = 0; M->snext = 0;
+                    }
+                    if (lane < RIM_STASH) M->sk[lane] = -1;
+                    active |= 1u << m;
+                }
+            }
+            need_pick = active;
+        }
+        if (cur > (have1 ? 1 : 0)) break;
     }
     if (lane == 0) {
         gp->ctr.samples += n_samp_all;
@@ -371,6 +420,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
         gp->ctr.inner_qags += n_qags;
         gp->member_passes += n_member_pass;
         gp->stash_filed += n_filed;
+        gp->stash_used += n_used;
         if (gp->hb) hb_store(gp->hb + 3, gp->ctr.steps);
     }
     wv_sync();                                  // results and sample counts are visible to every lane
@@ -611,6 +661,10 @@ __device__ __forceinline__ void symphony_group(const SymPoint &pt0, const DistPa
                 lb1 = wv_readlane(sel4(em1, rl0, rl1, rl2, rl3), ek1);
                 mk1 = ((unsigned) wv_readlane((int) gc.cmask, ek1) >> (4 * em1)) & 15u;
             }
+#if defined(RIM_WAVE_EMU)
+            if (lane == 0) { extern unsigned long long g_emu_hist[64]; g_emu_hist[24 + __builtin_popcount(mk0)]++; if (mk1) g_emu_hist[24 + __builtin_popcount(mk1)]++;
+                             g_emu_hist[32 + sel4(em0, ph0, ph1, ph2, ph3)] += __builtin_popcount(mk0) == 1; }
+#endif
 #if defined(RIM_WAVE_EMU) && defined(RIM_GROUP_TRACE)
             if (lane == 0) printf("  entry k=%d m=%d n=%.17g lobe=%d mask=%x | k=%d m=%d n=%.17g mask=%x  phases %d %d %d %d\n", ek0, em0, n0, lb0, mk0, ek1, em1, n1, mk1, ph0, ph1, ph2, ph3);
 #endif

@@ -45,6 +45,11 @@ CONFIGS = {
     "cfg3_thermal_8": (THERMAL_JUETTNER, 1, 0xFF),
     "cfg4_pitchypl_8": (PITCHY_PL, 2, 0xFF),
     "cfg5_pitchykappa_8": (PITCHY_KAPPA, 3, 0xFF),
+    # two variants SURVEY.md section 8d asks to be reported separately: the small-angle corner the tables leave out
+    # (theta log-uniform in [1e-3, 0.05]: harmonics up to 1e12 and beyond), and gamma_min fixed at 1 as in the
+    # reference's golden file (tests/symphony.rs:54-60) instead of log-uniform in [1, 30]
+    "cfg2_powerlaw_8_corner": (POWER_LAW, 0, 0xFF),
+    "cfg2_powerlaw_8_gmin1": (POWER_LAW, 0, 0xFF),
 }
 
 
@@ -55,10 +60,14 @@ def make_batch(config, n, start=0):
     idx = np.arange(start, start + n, dtype=np.uint64)
     s = _log(uniform01(seed, idx, 0), 0.1, 1e4)
     theta = _lin(uniform01(seed, idx, 1), 0.05, 1.52)
+    if config.endswith("_corner"):
+        theta = _log(uniform01(seed, idx, 1), 1e-3, 0.05)
     ones = np.ones(n)
     if kind == POWER_LAW:
         p = _lin(uniform01(seed, idx, 2), 1.5, 4.0)
         gmin = _log(uniform01(seed, idx, 3), 1.0, 30.0)
+        if config.endswith("_gmin1"):
+            gmin = ones.copy()
         params = [p, gmin, 1e12 * ones, 1e10 * ones]
     elif kind == THERMAL_JUETTNER:
         params = [_log(uniform01(seed, idx, 2), 0.1, 100.0)]

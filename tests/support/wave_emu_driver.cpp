@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../rimphony_amd/csrc/symphony_wave.h"
 #include "../../rimphony_amd/csrc/heyvaerts_wave.h"
+namespace rim { unsigned long long g_emu_hist[64]; }
 #include "../../rimphony_amd/csrc/symphony_group.h"
 
 using namespace rim;
@@ -194,6 +195,7 @@ extern "C" int emu_symphony_group(int kind, unsigned slots, int nmem, double s, 
             if (std::memcmp(&t.vals[i][m], &t.vals[0][m], 8) != 0 || t.stats[i][m] != t.stats[0][m]) uniform = 0;
     for (int m = 0; m < nmem; m++) { vals[m] = t.vals[0][m]; stats[m] = t.stats[0][m]; }
     work4[0] = t.samples; work4[1] = t.passes; work4[2] = t.inner_qags; work4[3] = t.member_passes; work4[4] = t.stash_filed;
+    for (int k = 0; k < 40; k++) { work4[5 + k] = rim::g_emu_hist[k]; rim::g_emu_hist[k] = 0; }
     return uniform;
 }
 

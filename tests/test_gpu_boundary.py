@@ -145,20 +145,39 @@ def test_api_refuses_views_and_wrong_dtypes(gpu_ctx):
         gpu_ctx.compute_batch_device(kind, d[0], d[1].cpu(), d[2:], mask)
 
 
-def test_against_literal_flavour_vectors(gpu_ctx):
-    """HIP vs the committed output of the oracle's literal flavour (glibc libm, unfused, GSL summation order): the
-    distribution bench.py reports as `parity`.  Bounds: the bulk agrees to rounding; the tail is the reference's own
-    noise-driven control flow, bounded here at the levels measured when the vectors were made."""
-    path = os.path.join(ROOT, "tests", "golden", "literal_cfg2_powerlaw_jI_aI.npz")
-    if not os.path.exists(path):
-        pytest.skip("literal vectors not generated")
+# Bounds of the HIP-vs-literal distance per table: 2 x the values measured in round 3 (profiles/r3_det_vs_literal_after_pair_terms.txt;
+# bench.py prints the live numbers as `parity`): (p99, max, coefficients beyond 1e-6, one-sided NaNs either way).  The tails of
+# the eight-coefficient tables are rho_Q / rho_V only; `parity.control` shows the same tails between
+# two builds of the literal flavour itself.
+LITERAL_BOUNDS = {
+    "cfg2_powerlaw_jI_aI": (4.3e-10, 4.0e-9, 0, 0),
+    "cfg2_powerlaw_8": (2.9e-8, 1.4e-5, 24, 2),
+    "cfg3_thermal_8": (1.1e-7, 1.8e-5, 24, 12),
+    "cfg4_pitchypl_8": (6.5e-7, 7.5e-5, 130, 10),
+    "cfg5_pitchykappa_8": (4.2e-7, 5.1e-5, 70, 26),
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(LITERAL_BOUNDS))
+def test_against_literal_flavour_vectors(gpu_ctx, cfg):
+    """HIP vs the committed output of the oracle's literal flavour (glibc libm, unfused, GSL summation order) on all five
+    tables: the distribution bench.py reports as `parity`.  A regression of the tail (3.7e-5 -> 1e-3) or of the one-sided
+    NaN counts fails here.  Symphony slots must agree on the NaN pattern EXACTLY since round 3 (the rule sums are formed
+    from QUADPACK's own pair terms: wave_qag.h)."""
+    path = os.path.join(ROOT, "tests", "golden", "literal_%s.npz" % cfg)
     z = np.load(path)
     n, start, m = int(z["n"]), int(z["start"]), int(z["mask"])
-    kind, _, s, th, params = workload.make_batch("cfg2_powerlaw_jI_aI", n, start=start)
+    kind, _, s, th, params = workload.make_batch(cfg, n, start=start)
     got = gpu_ctx.compute_batch(kind, s, th, params, m)
     r = workload.compare_tables(got, z["out"], m)
-    assert r["median"] < 1e-9 and r["within_1e-6"] > 0.95 and r["max"] < 1e-2, r
-    assert r["nan_only_here"] + r["nan_only_there"] <= 0.002 * r["coefficients"], r
+    p99, mx, beyond, onesided = LITERAL_BOUNDS[cfg]
+    assert r["median"] < 1e-13, r
+    assert r["p99"] <= p99 and r["max"] <= mx, r
+    assert round((1. - r["within_1e-6"]) * r["both_finite"]) <= beyond, r
+    assert r["nan_only_here"] + r["nan_only_there"] <= onesided, r
+    sym = workload.compare_tables(got, z["out"], m & 0x3F)
+    assert sym["nan_only_here"] == 0 and sym["nan_only_there"] == 0, sym
+    assert sym["max"] < 1e-7, sym          # the Symphony coefficients meet north_star's 1e-6 with a decade to spare
 
 
 def test_bench_launches_its_own_ranks():
@@ -168,11 +187,27 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["RIMPHONY_BENCH_REHEARSE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--points", "128", "--eight-rows", "0", "--cpu-sample", "0", "--no-parity"],
+                        "--points", "128", "--side-rows", "0", "--cpu-sample", "0", "--no-parity"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_runs_the_rccl_path_in_a_world_of_one():
+    """RCCL initialised and the device-tensor gather executed on real hardware (multi-GPU readiness):
+    bench.py with RIMPHONY_BENCH_FORCE_DIST=1 calls init_process_group("nccl") and runs sharding.gather_table's
+    dist.gather on CUDA tensors without the world-of-one short cut."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["RIMPHONY_BENCH_FORCE_DIST"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                        "--points", "256", "--side-rows", "0", "--cpu-sample", "0", "--no-parity"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "kernel_ms_min_max_over_ranks" in line["roofline"]      # only present when the collectives ran
 
 
 def test_f32_integrand_variant_error_envelope(gpu_ctx):
@@ -195,6 +230,22 @@ def test_f32_integrand_variant_error_envelope(gpu_ctx):
     with pytest.raises(capi.RimphonyError) as e:
         gpu_ctx.compute_batch(kind, s[:4], th[:4], [p[:4] for p in params], 0x3F, precision=7)
     assert "code -6" in str(e.value)
+
+
+def test_f32_integrand_is_refused_for_the_anisotropic_distributions(gpu_ctx):
+    """BASELINE configs[4] names pitchy_kappa with an fp32 integrand.  Measured on its own rows in round 2
+    (profiles/r2_f32_integrand_variant.txt): 1.53 x slower than fp64, 1.9 % new NaNs -- the quadratures of integrals that
+    cancel see the 1e-7 noise of the fp32 cores as round-off.  The precision is therefore not offered for the pitchy
+    kinds (RIMPHONY_ENOTSUP = -6, include/rimphony_hip.h says why); configs[4]'s table runs in fp64, and that run is held
+    to the oracle and to the literal vectors like every other table (test_against_literal_flavour_vectors[cfg5...])."""
+    from rimphony_amd import api
+    for cfg in ("cfg5_pitchykappa_8", "cfg4_pitchypl_8"):
+        kind, mask, s, th, params = workload.make_batch(cfg, 8)
+        with pytest.raises(capi.RimphonyError) as e:
+            gpu_ctx.compute_batch(kind, s, th, params, 0x3F, precision=api.PRECISION_F32_INTEGRAND)
+        assert "code -6" in str(e.value)
+        out = gpu_ctx.compute_batch(kind, s, th, params, 0x3F)          # the fp64 path serves the same rows
+        assert np.isfinite(out[:, :6]).any()
 
 
 def test_owner_fallback_changes_no_bit(gpu_ctx):

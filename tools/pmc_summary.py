@@ -12,6 +12,18 @@ for d in dirs:
             e["counters"][row["Counter_Name"]] = e["counters"].get(row["Counter_Name"], 0.) + float(row["Counter_Value"])
             for c in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"):
                 if c in row: e["launch"][c] = row[c]
-res = [{"kernel": k, "launch": v["launch"], "counters": v["counters"]} for k, v in acc.items() if "coop_kernel" in k or "symphony" in k]
+res = [{"kernel": k, "launch": v["launch"], "counters": v["counters"]} for k, v in acc.items() if "coop_kernel" in k or "symphony" in k or "group_kernel" in k]
+# the launch's own work counters (tools/one_batch.py prints them) next to the hardware counters, so that per-pass and
+# per-sample figures -- and bench.py's traffic check -- can be derived from this one file
+import re
+for d in dirs:
+    log = os.path.join(os.path.dirname(d.rstrip("/")), "log1.txt")
+    if os.path.exists(log):
+        m = re.search(r"^kernel ms ([0-9.]+) samples (\d+) passes (\d+) inner_qags (\d+)", open(log).read(), re.M)
+        if m:
+            for r in res:
+                if "Heyvaerts" not in r["kernel"]:
+                    r["work"] = {"kernel_ms_under_pmc": float(m.group(1)), "samples": int(m.group(2)), "passes": int(m.group(3)), "inner_qags": int(m.group(4))}
+        break
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
