@@ -229,3 +229,36 @@ def test_coefficient_tables_match_the_reference_sources(tmp_path):
         env = dict(os.environ, RIMPHONY_CHECK_DEV_BESSEL=str(bad))
         r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 1 and "DIFFERENT" in r.stdout, r.stdout[-1500:]
+
+
+def test_formulas_match_the_reference_sources(tmp_path):
+    """tools/check_formulas.py: everything that is a FORMULA in the reference's text -- the kinematics of gamma_integrand
+    with both branches of gamma sin(xi), the gamma limits, the prefactors, calc_f / calc_f_derivatives of the four
+    distributions, fill_coord_vars, dfdsigma, the limits of the Heyvaerts inner integrals, the final scalings and the
+    cgs layer -- is algebraically identical (sympy) in dev_symphony.h / symphony_wave.h / dev_heyvaerts.h /
+    heyvaerts_wave.h and in the oracle.  Only where the reference is mounted; one flipped sign in each of three files
+    must be caught."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference sources not mounted")
+    tool = os.path.join(root, "tools", "check_formulas.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ", 0 DIFFERENT" in r.stdout and r.stdout.count("identical") >= 120
+    mutations = (
+        ("RIMPHONY_CHECK_DEV_SYMPHONY", os.path.join(root, "rimphony_amd", "csrc", "dev_symphony.h"),
+         "const double m = rim_div_moderate(cos_th - beta * cos_xi, sin_th);", "const double m = rim_div_moderate(cos_th + beta * cos_xi, sin_th);"),
+        ("RIMPHONY_CHECK_DEV_HEYVAERTS", os.path.join(root, "rimphony_amd", "csrc", "dev_heyvaerts.h"),
+         "const double r = c.pomega - c.sigma * pt.cos_th;", "const double r = c.pomega + c.sigma * pt.cos_th;"),
+        ("RIMPHONY_CHECK_ORACLE_DIST", os.path.join(root, "oracle", "rimo_dist.c"),
+         "*dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);", "*dfdcx = f * k * cos_xi / (sin_xi * sin_xi);"),
+    )
+    for var, path, old, new in mutations:
+        src = open(path).read()
+        assert src.count(old) >= 1, old
+        bad = tmp_path / ("mutated_" + os.path.basename(path))
+        bad.write_text(src.replace(old, new, 1))
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: str(bad)}))
+        assert r.returncode == 1 and "DIFFERENT" in r.stdout, (var, r.stdout[-1500:])
