@@ -110,6 +110,9 @@ typedef struct rimphony_ctx rimphony_ctx;
  * off: slower, same results) or, with RIMPHONY_EXCLUSIVE=1 in the environment, is refused with RIMPHONY_EBUSY.
  * Calls on one context are serialised and ordered on the device whatever streams they name; different contexts
  * may be used from different threads freely.
+ * RIMPHONY_SYM_SOLO=1 runs the six Symphony coefficients one wave per (point, coefficient) as until round 2 instead of
+ * the coefficients of a point in lock-step; RIMPHONY_FARADAY_GROUP=1 runs rho_Q and rho_V of a point in lock-step as well
+ * (measured slower than one wave per coefficient, hence off).  Both for A/B measurements: the tables do not change.
  * RIMPHONY_OWNER_WAIT_US=<n> (test hook) shortens the 120 s an owner wave waits for its helpers before it recomputes
  * a published batch itself; results do not depend on it. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);
@@ -141,8 +144,9 @@ int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
  *   out[2], out[3]   Faraday: the same
  *   out[4]           Symphony group kernel: passes the coefficients would have executed one by one (out[4] / passes of
  *                    rimphony_last_work = how many coefficients an executed pass served on average)
- *   out[5]           ... rule sums filed ahead of a coefficient's own pick (the stash of symphony_group.h) */
-int rimphony_last_tail(rimphony_ctx *ctx, uint64_t out[6]);
+ *   out[5]           ... rule sums filed ahead of a coefficient's own pick (the stash of symphony_group.h)
+ *   out[6], out[7]   the same two for the Faraday pair (heyvaerts_group.h) */
+int rimphony_last_tail(rimphony_ctx *ctx, uint64_t out[8]);
 
 /* Duration of the most recent Symphony kernel launch of this context, measured
  * with HIP events recorded on the stream the kernel was launched on (waits for

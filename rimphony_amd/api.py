@@ -216,11 +216,12 @@ class Context:
     def last_tail(self):
         """Heaviest task of the last call per kernel (its chain of batches bounds the launch's tail) and the group
         kernel's sharing counters: include/rimphony_hip.h, rimphony_last_tail."""
-        o = (ctypes.c_uint64 * 6)()
+        o = (ctypes.c_uint64 * 8)()
         capi.check(self.lib.rimphony_last_tail(self.handle, o), "rimphony_last_tail")
         return {"symphony_heaviest_batches": int(o[0]), "symphony_heaviest_row": int(o[1]),
                 "faraday_heaviest_batches": int(o[2]), "faraday_heaviest_row": int(o[3]),
-                "member_passes": int(o[4]), "stash_filed": int(o[5])}
+                "member_passes": int(o[4]), "stash_filed": int(o[5]),
+                "faraday_member_passes": int(o[6]), "faraday_stash_filed": int(o[7])}
 
     def last_symphony_ms(self):
         ms = ctypes.c_float()

@@ -268,42 +268,24 @@ RIM_DEV double dfdsigma(const HeyPoint &pt, const DistParams &d, const HeyCoord 
     return g_term + mu_term;
 }
 
-template <int KIND>
-RIM_DEV double h_qr_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, const HeyCoord &c)
-{
-    const double po_sq = c.pomega * c.pomega;
-    const double smxox = (c.sigma - c.x) / c.x;
-    const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
-    double y1, y2;
-    RIM_PROF_COUNT(22, 1);
-#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
-    { const unsigned long long big = __ballot(!(g < RIM_G_APPROXIMATION_CUTOFF)); RIM_PROF_COUNT(23, big != 0 ? 1 : 0);
-      RIM_PROF_COUNT(24, __builtin_popcountll(big)); }
-#endif
-    if (g < RIM_G_APPROXIMATION_CUTOFF) {
-        double iv[4];
-        bessel_i_g4(hc, g, iv);
-        const double plus = iv[0], minus = iv[1], plus1 = iv[2], minus1 = iv[3];
-        y1 = RIM_FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
-        y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
-    } else {
-        double js, ys, jm1, ym1;
-        bessel_jy_set(c.sigma, c.x, true, &js, &ys, &jm1, &ym1);
-        const double jvp = jm1 - c.sigma * js / c.x;
-        const double yvp = ym1 - c.sigma * ys / c.x;
-        y1 = jvp * yvp;
-        y2 = -js * ys;
-    }
-    const double t1 = RIM_PI * RIM_PI * (c.x * c.x) * y1;
-    const double t2 = RIM_PI * RIM_PI * (c.pomega * c.pomega) * y2;
-    const double t3 = -RIM_PI * (2. * po_sq + pt.sigma0_sq) / rim_sqrt(po_sq + pt.sigma0_sq);
-    const double dfds = dfdsigma<KIND>(pt, d, c);
-    return RIM_INVERSE_C * (t1 + t2 + t3) * dfds;
-}
+// The inner integrand of the Faraday double integral in two pieces, so that rho_Q ("h") and rho_V ("f") of one
+// parameter point can share what depends on the sample only -- the coordinates, d f / d sigma (the distribution's
+// derivatives with their power and exponential), and the Bessel functions I_{+-1/3}, I_{+-2/3}(g) or J, Y of order sigma,
+// sigma - 1 (heyvaerts.rs:302-468 evaluates them once per element) -- and differ in the element's closing formula.
+struct HeyShared {
+    HeyCoord c;
+    double dfds;
+    // quasi-resonant elements (heyvaerts.rs:302-373, 400-447)
+    bool small_g;                   // g < G_APPROXIMATION_CUTOFF: the I_nu(g) forms
+    double g, iv0, iv1, iv2, iv3;   // I_{2/3}, I_{-2/3}, I_{1/3}, I_{-1/3} of g
+    double js, ys, jm1, ym1;        // J_sigma, Y_sigma, J_{sigma-1}, Y_{sigma-1} of x (ym1 only for "h")
+    // non-resonant elements (heyvaerts.rs:379-394, 453-468)
+    double a1, a2, xa1p, x_sq, u, u2;
+};
 
-// The non-resonant elements (heyvaerts.rs:379-394, 453-468) divide by the powers 1/2, 1, 3/2, 2 and 5/2 of
-// sigma^2 - x^2 eleven times between them.  Here every one is a product of powers of u = 1 / sqrt(sigma^2 - x^2): one
-// square root and one division per sample (the deterministic oracle does the same; the literal one divides).
+// The non-resonant elements divide by the powers 1/2, 1, 3/2, 2 and 5/2 of sigma^2 - x^2 eleven times between them.
+// Here every one is a product of powers of u = 1 / sqrt(sigma^2 - x^2): one square root and one division per sample
+// (the deterministic oracle does the same; the literal one divides).
 RIM_DEV void nr_common(const HeyCoord &c, double &a1, double &a2, double &xa1p, double &x_sq, double &u, double &u2)
 {
     const double s_sq = c.sigma * c.sigma;
@@ -316,53 +298,92 @@ RIM_DEV void nr_common(const HeyCoord &c, double &a1, double &a2, double &xa1p, 
     xa1p = -5. / 12. * (s_sq * x_sq) * (u2 * u2);
 }
 
+// want_h: the "h" element will be asked for (it needs Y_{sigma-1} on the J/Y branch)
 template <int KIND>
-RIM_DEV double h_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
+RIM_DEV HeyShared hey_shared(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, bool qr, double fixed, double v, bool want_h)
 {
-    double a1, a2, xa1p, x_sq, u, u2;
-    nr_common(c, a1, a2, xa1p, x_sq, u, u2);
-    const double u3 = u2 * u;
-    const double t1 = (6. * a2 - a1 * a1 + xa1p) * u + a1 * x_sq * u3
-        - (x_sq * x_sq) * (u3 * u2) * 0.125;
-    const double t2 = (6. * a2 - a1 * a1) * u3;
-    const double u1 = 2. * t1 - pt.sigma0_sq * t2;
-    const double dfds = dfdsigma<KIND>(pt, d, c);
-    return RIM_PI * RIM_INVERSE_C * u1 * dfds;
-}
-
-template <int KIND>
-RIM_DEV double f_qr_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, const HeyCoord &c)
-{
-    const double g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
-    double y;
-    if (g < RIM_G_APPROXIMATION_CUTOFF) {
-        double iv[4];
-        bessel_i_g4(hc, g, iv);
-        y = RIM_INVERSE_SQRT_3
-            * g
-            * (iv[1] - iv[0])
-            * (iv[3] + iv[2]);
+    HeyShared sh;
+    sh.small_g = true;
+    sh.g = 0.; sh.iv0 = 0.; sh.iv1 = 0.; sh.iv2 = 0.; sh.iv3 = 0.;
+    sh.js = 0.; sh.ys = 0.; sh.jm1 = 0.; sh.ym1 = 0.;
+    sh.a1 = 0.; sh.a2 = 0.; sh.xa1p = 0.; sh.x_sq = 0.; sh.u = 0.; sh.u2 = 0.;
+    if (qr) {
+        RIM_HIT(26);
+        sh.c = fill_coord_vars(pt, fixed, v);
+        const HeyCoord &c = sh.c;
+        sh.g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
+        RIM_PROF_COUNT(22, 1);
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        { const unsigned long long big = __ballot(!(sh.g < RIM_G_APPROXIMATION_CUTOFF)); RIM_PROF_COUNT(23, big != 0 ? 1 : 0);
+          RIM_PROF_COUNT(24, __builtin_popcountll(big)); }
+#endif
+        sh.small_g = sh.g < RIM_G_APPROXIMATION_CUTOFF;
+        if (sh.small_g) {
+            double iv[4];
+            bessel_i_g4(hc, sh.g, iv);
+            sh.iv0 = iv[0]; sh.iv1 = iv[1]; sh.iv2 = iv[2]; sh.iv3 = iv[3];
+        } else {
+            bessel_jy_set(c.sigma, c.x, want_h, &sh.js, &sh.ys, &sh.jm1, &sh.ym1);
+        }
     } else {
-        double js, ys, jm1, ym1;
-        bessel_jy_set(c.sigma, c.x, false, &js, &ys, &jm1, &ym1);
-        const double jvp = jm1 - c.sigma * js / c.x;
-        y = -c.x * jvp * ys;
+        RIM_HIT(25);
+        sh.c = fill_coord_vars(pt, v, fixed);
+        nr_common(sh.c, sh.a1, sh.a2, sh.xa1p, sh.x_sq, sh.u, sh.u2);
     }
-    const double dfds = dfdsigma<KIND>(pt, d, c);
-    return -(2. * RIM_PI) * RIM_INVERSE_C * c.pomega * (RIM_PI * y - 1.) * dfds;
+    sh.dfds = dfdsigma<KIND>(pt, d, sh.c);
+    return sh;
 }
 
-template <int KIND>
-RIM_DEV double f_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCoord &c)
+// the element of Stokes parameter `stokes` (Q: "h", heyvaerts.rs:302-394; V: "f", :400-468) from the shared part
+RIM_DEV double hey_member(const HeyPoint &pt, int stokes, bool qr, const HeyShared &sh)
 {
-    double a1, a2, xa1p, x_sq, u, u2;
-    nr_common(c, a1, a2, xa1p, x_sq, u, u2);
+    const HeyCoord &c = sh.c;
+    if (qr) {
+        if (stokes == STOKES_Q) {
+            const double po_sq = c.pomega * c.pomega;
+            const double smxox = (c.sigma - c.x) / c.x;
+            double y1, y2;
+            if (sh.small_g) {
+                const double plus = sh.iv0, minus = sh.iv1, plus1 = sh.iv2, minus1 = sh.iv3;
+                y1 = RIM_FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
+                y2 = 0.5 * RIM_FOUR_OVER_SQRT_27 * smxox * (minus1 - plus1) * (minus1 + plus1);
+            } else {
+                const double jvp = sh.jm1 - c.sigma * sh.js / c.x;
+                const double yvp = sh.ym1 - c.sigma * sh.ys / c.x;
+                y1 = jvp * yvp;
+                y2 = -sh.js * sh.ys;
+            }
+            const double t1 = RIM_PI * RIM_PI * (c.x * c.x) * y1;
+            const double t2 = RIM_PI * RIM_PI * (c.pomega * c.pomega) * y2;
+            const double t3 = -RIM_PI * (2. * po_sq + pt.sigma0_sq) / rim_sqrt(po_sq + pt.sigma0_sq);
+            return RIM_INVERSE_C * (t1 + t2 + t3) * sh.dfds;
+        }
+        double y;
+        if (sh.small_g) {
+            y = RIM_INVERSE_SQRT_3
+                * sh.g
+                * (sh.iv1 - sh.iv0)
+                * (sh.iv3 + sh.iv2);
+        } else {
+            const double jvp = sh.jm1 - c.sigma * sh.js / c.x;
+            y = -c.x * jvp * sh.ys;
+        }
+        return -(2. * RIM_PI) * RIM_INVERSE_C * c.pomega * (RIM_PI * y - 1.) * sh.dfds;
+    }
+    const double a1 = sh.a1, a2 = sh.a2, xa1p = sh.xa1p, x_sq = sh.x_sq, u = sh.u, u2 = sh.u2;
+    if (stokes == STOKES_Q) {
+        const double u3 = u2 * u;
+        const double t1 = (6. * a2 - a1 * a1 + xa1p) * u + a1 * x_sq * u3
+            - (x_sq * x_sq) * (u3 * u2) * 0.125;
+        const double t2 = (6. * a2 - a1 * a1) * u3;
+        const double u1 = 2. * t1 - pt.sigma0_sq * t2;
+        return RIM_PI * RIM_INVERSE_C * u1 * sh.dfds;
+    }
     const double z =
         0.5 * x_sq * (u2 * u)
         + (6. * a2 + xa1p - a1 * a1) * u2
         + 1.5 * a1 * x_sq * (u2 * u2);
-    const double dfds = dfdsigma<KIND>(pt, d, c);
-    return -2. * RIM_PI * RIM_INVERSE_C * z * c.pomega * dfds;
+    return -2. * RIM_PI * RIM_INVERSE_C * z * c.pomega * sh.dfds;
 }
 
 // The inner integrand of either regime: `qr` selects quasi-resonant (integration variable
@@ -370,19 +391,10 @@ RIM_DEV double f_nr_element(const HeyPoint &pt, const DistParams &d, const HeyCo
 template <int KIND>
 RIM_DEV double hey_element(const HeyPoint &pt, const DistParams &d, const HeyConsts &hc, bool qr, double fixed, double v)
 {
-    if (qr) {
-        RIM_HIT(26);
-        RIM_PROF_T(t_qr);
-        const HeyCoord c = fill_coord_vars(pt, fixed, v);
-        const double r = pt.stokes == STOKES_Q ? h_qr_element<KIND>(pt, d, hc, c) : f_qr_element<KIND>(pt, d, hc, c);
-        RIM_PROF_ADD(19, t_qr);
-        return r;
-    }
-    RIM_HIT(25);
-    RIM_PROF_T(t_nr);
-    const HeyCoord c = fill_coord_vars(pt, v, fixed);
-    const double r = pt.stokes == STOKES_Q ? h_nr_element<KIND>(pt, d, c) : f_nr_element<KIND>(pt, d, c);
-    RIM_PROF_ADD(18, t_nr);
+    RIM_PROF_T(t_el);
+    const HeyShared sh = hey_shared<KIND>(pt, d, hc, qr, fixed, v, pt.stokes == STOKES_Q);
+    const double r = hey_member(pt, pt.stokes, qr, sh);
+    RIM_PROF_ADD(qr ? 19 : 18, t_el);
     return r;
 }
 

@@ -3,11 +3,15 @@
 #define RIM_GROUP_LAUNCH_H
 
 #include "symphony_group.h"
+#include "heyvaerts_group.h"
 #include "coop_common.h"
 
 // waves per SIMD the register allocator must leave room for (4 x 16 waves per CU: 10 KB of LDS each)
 #ifndef RIM_GROUP_WAVES
 #define RIM_GROUP_WAVES 4
+#endif
+#ifndef RIM_HEY_GROUP_WAVES
+#define RIM_HEY_GROUP_WAVES 4
 #endif
 // entries of one published round: up to 62 lanes x RIM_GROUP classes
 #define RIM_GROUP_ENTRIES 248
@@ -37,7 +41,9 @@ struct GroupArgs {
     int coop;                       // cooperative tail on
 };
 
-const void *rim_group_kernel(int kind);
-int rim_group_launch(int kind, unsigned grid, hipStream_t st, const GroupArgs &ga);
+// faraday = 0: the Symphony groups ({j_I, alpha_I, j_Q, alpha_Q}, {j_V, alpha_V}); 1: the Faraday pair {rho_Q, rho_V}
+const void *rim_group_kernel(int kind, int faraday);
+int rim_group_waves(int faraday);
+int rim_group_launch(int kind, int faraday, unsigned grid, hipStream_t st, const GroupArgs &ga);
 
 #endif

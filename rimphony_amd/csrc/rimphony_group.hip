@@ -14,11 +14,98 @@
 #include <hip/hip_runtime.h>
 #include "../../include/rimphony_hip.h"
 #include "symphony_group.h"
+#include "heyvaerts_group.h"
 #include "rimphony_internal.h"
 #include "coop_common.h"
 #include "group_launch.h"
 
 using namespace rim;
+
+// ---- the two problems the group kernel runs ---------------------------------------------------------------------
+// A problem supplies the context of a task, the members' state machines (begin / post / consume / result: the solo
+// code of symphony_wave.h / heyvaerts_wave.h, one instance per member), whose turn it is, and the lock-step
+// evaluation of one or two merged entries.  A member is named by its output slot (lib.rs:176-177).
+template <int KIND>
+struct SymGroupProblem {
+    typedef TaskState Task;
+    typedef GroupPark Park;
+    struct Ctx { SymPoint pt; DistParams d; };
+    enum : int { QUEUE = 0, TAIL_WORD = 14, STATS_WORD = 8, WAVES = RIM_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1 };
+    static __device__ __forceinline__ void init(const SymArgs &, Ctx &c, double *)
+    { c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.coeff = 0; c.pt.stokes = 0; }
+    static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned slots, Ctx &c, double &norm)
+    { load_context<KIND>(a, i, group_slot(slots, 0), c.pt, c.d, norm); }
+    static __device__ __forceinline__ SymPoint member_point(const Ctx &c, int slot)
+    { SymPoint pt = c.pt; pt.coeff = slot & 1; pt.stokes = slot >> 1; return pt; }
+    static __device__ __forceinline__ void begin(const Ctx &c, int slot, Task &T) { sym_begin(member_point(c, slot), T); }
+    static __device__ __forceinline__ void uniformize(Task &T) { task_uniformize(T); }
+    static __device__ __forceinline__ bool done(const Task &T) { return T.phase == PH_DONE; }
+    static __device__ __forceinline__ int batches(const Task &T) { return T.batches; }
+    static __device__ __forceinline__ bool post(const Ctx &c, int slot, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
+    { return sym_post(member_point(c, slot), g, outer, T, B); }
+    static __device__ __forceinline__ void consume(const Ctx &c, int slot, const GKLane &g, const IStore &outer, Task &T,
+                                                   const SymBatch &B, double gval, int bst)
+    { sym_consume(member_point(c, slot), g, outer, T, B, gval, bst); }
+    static __device__ __forceinline__ double result(const Ctx &c, int slot, const Task &T, int &st)
+    { return sym_result(member_point(c, slot), T, st); }
+    static __device__ __forceinline__ unsigned turn(const Task *park, unsigned alive) { return group_turn(park, alive); }
+    static __device__ __forceinline__ void eval(const Ctx &c, unsigned slots, const GKLane &g, double *lds, double *spill, Park *gp,
+                                                double x0, int t0, unsigned m0, double x1, int t1, unsigned m1)
+    { sym_eval_group<KIND>(c.pt, c.d, slots, g, lds, spill, gp, x0, t0, m0, x1, t1, m1); }
+};
+
+template <int KIND>
+struct HeyGroupProblem {
+    typedef HeyTask Task;
+    typedef GroupParkBase Park;
+    struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
+    enum : int { QUEUE = 4, TAIL_WORD = 15, STATS_WORD = 10, WAVES = RIM_HEY_GROUP_WAVES, EXTRA_LDS_DOUBLES = 4 * RIM_SERIES_LDS_ROW };
+    static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
+    {
+        for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64) {
+            const int j = i / RIM_SERIES_LDS_ROW, r = i % RIM_SERIES_LDS_ROW;
+            extra_lds[i] = a.series_tab[j * RIM_SERIES_ROW + r];
+        }
+        __syncthreads();
+        c.hc = hey_consts(a.series_tab, extra_lds);
+        c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.stokes = STOKES_Q;
+    }
+    static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned, Ctx &c, double &norm)
+    {
+        HeyPoint &pt = c.pt;
+        pt.s = uni(a.s[i]);
+        rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
+        pt.sin_th = uni(pt.sin_th);
+        pt.cos_th = uni(pt.cos_th);
+        pt.sigma0 = uni(pt.s * pt.sin_th);
+        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
+        pt.stokes = STOKES_Q;
+        load_params<KIND>(a.pp, i, c.d);
+        norm = uni(a.norm[i]);
+        dist_prepare<KIND>(c.d, norm);
+#pragma unroll
+        for (int k = 0; k < 5; k++) c.d.par[k] = uni(c.d.par[k]);
+        c.d.inv_gamma_cutoff = uni(c.d.inv_gamma_cutoff);
+        c.d.inv_kappa_width = uni(c.d.inv_kappa_width);
+        c.d.neg_inverse_t = uni(c.d.neg_inverse_t);
+    }
+    static __device__ __forceinline__ HeyPoint member_point(const Ctx &c, int slot)
+    { HeyPoint pt = c.pt; pt.stokes = hey_slot_stokes(slot); return pt; }
+    static __device__ __forceinline__ void begin(const Ctx &c, int slot, Task &T) { hey_begin(member_point(c, slot), T); }
+    static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }
+    static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
+    static __device__ __forceinline__ int batches(const Task &T) { return T.batches; }
+    static __device__ __forceinline__ bool post(const Ctx &c, int slot, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
+    { return hey_post(member_point(c, slot), g, outer, T, B); }
+    static __device__ __forceinline__ void consume(const Ctx &c, int slot, const GKLane &g, const IStore &outer, Task &T,
+                                                   const SymBatch &B, double gval, int bst)
+    { hey_consume(member_point(c, slot), g, outer, T, B, gval, bst); }
+    static __device__ __forceinline__ double result(const Ctx &, int, const Task &T, int &st) { return hey_result(T, st); }
+    static __device__ __forceinline__ unsigned turn(const Task *park, unsigned alive) { return hey_group_turn(park, alive); }
+    static __device__ __forceinline__ void eval(const Ctx &c, unsigned slots, const GKLane &g, double *lds, double *spill, Park *gp,
+                                                double x0, int t0, unsigned m0, double x1, int t1, unsigned m1)
+    { hey_eval_group<KIND>(c.pt, c.d, c.hc, slots, g, lds, spill, gp, x0, t0, m0, x1, t1, m1); }
+};
 
 // claim the next unevaluated entry of batch `seq` on a group slot; -1 if there is none (or the batch is over)
 __device__ __forceinline__ int group_claim(GroupSlot *slot, unsigned seq, int lane)
@@ -36,14 +123,15 @@ __device__ __forceinline__ int group_claim(GroupSlot *slot, unsigned seq, int la
     return __builtin_amdgcn_readfirstlane(k);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga)
+template <class P>
+__global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
 {
     const SymArgs &a = ga.base;
     __shared__ double s_tab[96];
     __shared__ double s_ginner[RIM_GROUP * RIM_ISTORE_DOUBLES(CAP_GINNER)];
-    __shared__ TaskState s_park[RIM_GROUP];
-    __shared__ GroupPark s_gp;
+    __shared__ typename P::Task s_park[RIM_GROUP];
+    __shared__ typename P::Park s_gp;
+    __shared__ double s_extra[P::EXTRA_LDS_DOUBLES];
     const GKLane g = gk_lane_init(s_tab);
     const int lane = g.lane;
     double *const inner_spill = ga.gspill + (size_t) blockIdx.x * SPILL_GROUP_DOUBLES_PER_WAVE;
@@ -68,11 +156,10 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
     unsigned n_polls = 0;
 
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned long long) ga.ngroups;
-    SymPoint pt0;                          // context of the entries being evaluated (own task or a helped one)
-    DistParams dist;
+    typename P::Ctx cx;                    // context of the entries being evaluated (own task or a helped one)
+    P::init(a, cx, s_extra);
     unsigned slots = 0;
-    pt0.s = 0.; pt0.cos_th = 0.; pt0.sin_th = 0.; pt0.coeff = 0; pt0.stokes = 0;
-    unsigned long long *const queue = a.queue;
+    unsigned long long *const queue = a.queue + P::QUEUE;
     size_t own_i = 0;
     unsigned own_slots = 0;
     int own_nmem = 0, own_group = 0;
@@ -117,7 +204,7 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                 own_slots = own_group ? ga.gslots[1] : ga.gslots[0];
                 own_nmem = own_group ? ga.gnmem[1] : ga.gnmem[0];
                 double norm;
-                load_context<KIND>(a, own_i, group_slot(own_slots, 0), pt0, dist, norm);
+                P::load(a, own_i, own_slots, cx, norm);
                 slots = own_slots;
                 __syncthreads();
                 if (!(norm == norm)) {
@@ -132,13 +219,11 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                 }
                 alive = 0;
                 for (int m = 0; m < own_nmem; m++) {
-                    SymPoint pt = pt0;
-                    pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
-                    TaskState T0;
-                    sym_begin(pt, T0);
+                    typename P::Task T0;
+                    P::begin(cx, group_slot(own_slots, m), T0);
                     __syncthreads();
                     if (lane == 0) s_park[m] = T0;
-                    if (T0.phase != PH_DONE) alive |= 1u << m;
+                    if (!P::done(T0)) alive |= 1u << m;
                 }
                 __syncthreads();
                 have_task = true;
@@ -146,18 +231,16 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
             if (!alive) {
                 // every member has finished: results (symphony.rs:144-183)
                 for (int m = 0; m < own_nmem; m++) {
-                    SymPoint pt = pt0;
-                    pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
-                    TaskState T = s_park[m];
-                    task_uniformize(T);
+                    typename P::Task T = s_park[m];
+                    P::uniformize(T);
                     int st = 0;
-                    const double val = sym_result(pt, T, st);
+                    const int sl = group_slot(own_slots, m);
+                    const double val = P::result(cx, sl, T, st);
                     if (lane == 0) {
-                        const int sl = group_slot(own_slots, m);
                         a.out[own_i * 8 + sl] = val;
                         if (a.status) a.status[own_i * 8 + sl] = st;
                         // the heaviest member of the launch: its sequential chain of batches bounds the launch's tail
-                        atomicMax(a.queue + 14, ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));
+                        atomicMax(a.queue + P::TAIL_WORD, ((unsigned long long) P::batches(T) << 24) | ((unsigned long long) own_i & 0xffffffull));
                     }
                 }
                 __syncthreads();
@@ -165,16 +248,14 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                 continue;
             }
             // the members that are furthest behind post their batches (symphony_group.h: group_turn)
-            const unsigned turn = group_turn(s_park, alive);
+            const unsigned turn = P::turn(s_park, alive);
             for (unsigned rem = turn; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
-                SymPoint pt = pt0;
-                pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
                 const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
-                TaskState T = s_park[m];
-                task_uniformize(T);
+                typename P::Task T = s_park[m];
+                P::uniformize(T);
                 SymBatch B;
-                const bool ok = sym_post(pt, g, outer, T, B);
+                const bool ok = P::post(cx, group_slot(own_slots, m), g, outer, T, B);
                 __syncthreads();
                 if (lane == 0) s_park[m] = T;
                 if (!ok) { alive &= ~(1u << m); continue; }
@@ -317,7 +398,7 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                     double norm;
                     const size_t hi = (size_t) bcast_u64(bget(&src->point));
                     slots = (unsigned) __builtin_amdgcn_readfirstlane((int) bget(&src->slots));
-                    load_context<KIND>(a, hi, group_slot(slots, 0), pt0, dist, norm);
+                    P::load(a, hi, slots, cx, norm);
                     work_i = hi;
                     ctx_loaded = true;
                     if (counted_idle) {
@@ -352,7 +433,7 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
                 if (ek0 < 0) break;
             }
             got += 1;
-            sym_eval_group<KIND>(pt0, dist, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
+            P::eval(cx, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
             if (shared) {
                 // hand the members' values, status bits and sample counts back through the board
                 if (lane == 0) {
@@ -459,21 +540,19 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
         // ---------- every member that posted consumes its results ----------
         for (unsigned rem = posted; rem; rem &= rem - 1) {
             const int m = __builtin_ctz(rem);
-            SymPoint pt = pt0;
-            pt.coeff = group_slot(own_slots, m) & 1; pt.stokes = group_slot(own_slots, m) >> 1;
             const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
-            TaskState T = s_park[m];
-            task_uniformize(T);
+            typename P::Task T = s_park[m];
+            P::uniformize(T);
             SymBatch B;
             B.req_n = sel4(m, rq0, rq1, rq2, rq3);
             B.req_lobe = sel4(m, rl0, rl1, rl2, rl3);
             B.req_active = ((act >> m) & 1u) != 0;
             B.n_req = sel4(m, nq0, nq1, nq2, nq3);
             B.phase = sel4(m, ph0, ph1, ph2, ph3);
-            sym_consume(pt, g, outer, T, B, sel4(m, gv0, gv1, gv2, gv3), uni(sel4(m, bs0, bs1, bs2, bs3)));
+            P::consume(cx, group_slot(own_slots, m), g, outer, T, B, sel4(m, gv0, gv1, gv2, gv3), uni(sel4(m, bs0, bs1, bs2, bs3)));
             __syncthreads();
             if (lane == 0) s_park[m] = T;
-            if (T.phase == PH_DONE) alive &= ~(1u << m);
+            if (P::done(T)) alive &= ~(1u << m);
         }
         __syncthreads();
     }
@@ -483,32 +562,57 @@ __global__ __launch_bounds__(64, RIM_GROUP_WAVES) void group_kernel(GroupArgs ga
         atomicAdd(queue + 1, s_gp.ctr.samples);
         atomicAdd(queue + 2, s_gp.ctr.steps);
         atomicAdd(queue + 3, s_gp.ctr.inner_qags);
-        atomicAdd(a.queue + 8, s_gp.member_passes);
-        atomicAdd(a.queue + 9, s_gp.stash_filed);
+        atomicAdd(a.queue + P::STATS_WORD, s_gp.member_passes);
+        atomicAdd(a.queue + P::STATS_WORD + 1, s_gp.stash_filed);
     }
 }
 
 // ---- launch interface (group_launch.h) -----------------------------------------------------------------------
-template <int KIND>
-static const void *kernel_ptr() { return reinterpret_cast<const void *>(group_kernel<KIND>); }
+template <class P>
+static const void *kernel_ptr() { return reinterpret_cast<const void *>(group_kernel<P>); }
 
-const void *rim_group_kernel(int kind)
+const void *rim_group_kernel(int kind, int faraday)
 {
+    if (faraday) {
+        switch (kind) {
+        case 0: return kernel_ptr<HeyGroupProblem<0>>();
+        case 1: return kernel_ptr<HeyGroupProblem<1>>();
+        case 2: return kernel_ptr<HeyGroupProblem<2>>();
+        default: return kernel_ptr<HeyGroupProblem<3>>();
+        }
+    }
     switch (kind) {
-    case 0: return kernel_ptr<0>();
-    case 1: return kernel_ptr<1>();
-    case 2: return kernel_ptr<2>();
-    default: return kernel_ptr<3>();
+    case 0: return kernel_ptr<SymGroupProblem<0>>();
+    case 1: return kernel_ptr<SymGroupProblem<1>>();
+    case 2: return kernel_ptr<SymGroupProblem<2>>();
+    default: return kernel_ptr<SymGroupProblem<3>>();
     }
 }
 
-int rim_group_launch(int kind, unsigned grid, hipStream_t st, const GroupArgs &ga)
+int rim_group_waves(int faraday) { return faraday ? RIM_HEY_GROUP_WAVES : RIM_GROUP_WAVES; }
+
+template <class P>
+static void launch(unsigned grid, hipStream_t st, const GroupArgs &ga)
 {
-    switch (kind) {
-    case 0: hipLaunchKernelGGL(group_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
-    case 1: hipLaunchKernelGGL(group_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
-    case 2: hipLaunchKernelGGL(group_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
-    default: hipLaunchKernelGGL(group_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga); break;
+    hipLaunchKernelGGL(group_kernel<P>, dim3(grid), dim3(64), RIM_DYN_LDS, st, ga);
+}
+
+int rim_group_launch(int kind, int faraday, unsigned grid, hipStream_t st, const GroupArgs &ga)
+{
+    if (faraday) {
+        switch (kind) {
+        case 0: launch<HeyGroupProblem<0>>(grid, st, ga); break;
+        case 1: launch<HeyGroupProblem<1>>(grid, st, ga); break;
+        case 2: launch<HeyGroupProblem<2>>(grid, st, ga); break;
+        default: launch<HeyGroupProblem<3>>(grid, st, ga); break;
+        }
+    } else {
+        switch (kind) {
+        case 0: launch<SymGroupProblem<0>>(grid, st, ga); break;
+        case 1: launch<SymGroupProblem<1>>(grid, st, ga); break;
+        case 2: launch<SymGroupProblem<2>>(grid, st, ga); break;
+        default: launch<SymGroupProblem<3>>(grid, st, ga); break;
+        }
     }
     return hipGetLastError() == hipSuccess ? RIMPHONY_OK : RIMPHONY_EHIP;
 }

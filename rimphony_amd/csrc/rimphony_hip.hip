@@ -817,8 +817,9 @@ struct rimphony_ctx {
     size_t gspill_waves;
     GroupSlot *d_gboard;            // [gboard_slots] + flag words behind
     size_t gboard_slots;
-    int resident_group[4];
+    int resident_group[2][4];       // [Symphony groups / Faraday pair][kind]
     int sym_solo;                   // RIMPHONY_SYM_SOLO=1: one wave per (point, coefficient), the round-2 kernel (A/B measurements)
+    int faraday_group;              // RIMPHONY_FARADAY_GROUP=1: rho_Q and rho_V of a point in lock-step (measured slower: DESIGN.md section 5)
 };
 
 // ---- last error (thread-local text; the codes are in rimphony_hip.h) ---------------------------
@@ -927,6 +928,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     if (!c->mu) { delete c; return RIMPHONY_ENOMEM; }
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
+    { const char *e = getenv("RIMPHONY_FARADAY_GROUP"); c->faraday_group = (e && e[0] == '1'); }
     c->shared_mode = take_device_lock(device, &c->lock_fd);
     if (c->shared_mode) {
         const char *e = getenv("RIMPHONY_EXCLUSIVE");
@@ -1142,31 +1144,34 @@ static int launch_heyvaerts(rimphony_ctx *c, const SymArgs &a, hipStream_t st)
     return rc;
 }
 
-// The Symphony slots of a batch as (point, group) tasks: group 0 = the selected ones of {j_I, alpha_I, j_Q, alpha_Q},
-// group 1 = those of {j_V, alpha_V} (rimphony_group.hip / symphony_group.h).
-static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t coeff_mask, hipStream_t st)
+// The slots of a batch as (point, group) tasks (rimphony_group.hip).  Symphony: group 0 = the selected ones of
+// {j_I, alpha_I, j_Q, alpha_Q}, group 1 = those of {j_V, alpha_V} (symphony_group.h); Faraday: the one group
+// {rho_Q, rho_V} (heyvaerts_group.h).
+static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t coeff_mask, int faraday, hipStream_t st)
 {
     GroupArgs ga;
     ga.base = a;
     ga.ngroups = 0;
     ga.gslots[0] = ga.gslots[1] = 0;
     ga.gnmem[0] = ga.gnmem[1] = 0;
-    for (int grp = 0; grp < 2; grp++) {
+    for (int grp = 0; grp < (faraday ? 1 : 2); grp++) {
         unsigned packed = 0;
         int nm = 0;
-        for (int k = grp ? 4 : 0; k < (grp ? 6 : 4); k++)
+        const int lo = faraday ? 6 : (grp ? 4 : 0), hi = faraday ? 8 : (grp ? 6 : 4);
+        for (int k = lo; k < hi; k++)
             if (coeff_mask & (1u << k)) { packed |= (unsigned) k << (4 * nm); nm++; }
         if (nm) { ga.gslots[ga.ngroups] = packed; ga.gnmem[ga.ngroups] = nm; ga.ngroups++; }
     }
     if (ga.ngroups == 0) return RIMPHONY_OK;
     const unsigned long long ntasks = (unsigned long long) a.n * (unsigned) ga.ngroups;
     const unsigned long long want_waves = (ntasks > (1ull << 40) || c->no_assist) ? ntasks : ntasks * 64ull;
-    int *resident = &c->resident_group[kind];
-    const void *kfn = rim_group_kernel(kind);
+    int *resident = &c->resident_group[faraday ? 1 : 0][kind];
+    const void *kfn = rim_group_kernel(kind, faraday);
+    const int waves = rim_group_waves(faraday);
     if (*resident == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 64, RIM_DYN_LDS) != hipSuccess || nb < 1) nb = 4;
-        *resident = nb < 4 * RIM_GROUP_WAVES ? nb : 4 * RIM_GROUP_WAVES;
+        *resident = nb < 4 * waves ? nb : 4 * waves;
     }
     int resident_per_cu = *resident;
     {   // the LDS limit re-derived with the 512-byte allocation granule and one granule of slack (see launch_coop)
@@ -1207,11 +1212,11 @@ static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t co
     // slots need no reset: an entry is written before its round is opened)
     HIP_TRY(hipMemset2DAsync(c->d_gboard, sizeof(GroupSlot), 0, 32, grid, st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, ga.base.board_flags, grid);
-    HIP_TRY(hipEventRecord(c->ev_start, st));
-    const int rc = rim_group_launch(kind, grid, st, ga);
+    HIP_TRY(hipEventRecord(faraday ? c->ev_fstart : c->ev_start, st));
+    const int rc = rim_group_launch(kind, faraday, grid, st, ga);
     if (rc) { rim_set_last_error("group_kernel launch", hipGetErrorString(hipGetLastError())); return rc; }
-    HIP_TRY(hipEventRecord(c->ev_stop, st));
-    c->ev_valid = 1;
+    HIP_TRY(hipEventRecord(faraday ? c->ev_fstop : c->ev_stop, st));
+    if (faraday) c->evf_valid = 1; else c->ev_valid = 1;
     return RIMPHONY_OK;
 }
 
@@ -1330,7 +1335,7 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
             else rc = launch_symphony<1, 1>(c, a, st);
         } else if (!c->sym_solo) {
             // the coefficients of a point that share their samples advance in lock-step on one wave
-            rc = launch_group(c, kind, a, coeff_mask, st);
+            rc = launch_group(c, kind, a, coeff_mask, 0, st);
         } else {
             switch (kind) {
             case 0: rc = launch_symphony<0>(c, a, st); break;
@@ -1341,7 +1346,13 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
         }
         if (rc) return rc;
     }
-    if (fa.nslots > 0) {
+    if (fa.nslots > 0 && c->faraday_group) {
+        // rho_Q and rho_V of a point in lock-step (heyvaerts_group.h): they share their samples' coordinates, distribution
+        // derivatives and Bessel functions.  Bit-identical, and measured SLOWER than one wave per coefficient (an executed
+        // pass serves 1.38 coefficients and costs 1.6 solo passes: DESIGN.md section 5) -- off unless asked for.
+        rc = launch_group(c, kind, fa, coeff_mask, 1, st);
+        if (rc) return rc;
+    } else if (fa.nslots > 0) {
         switch (kind) {
         case 0: rc = launch_heyvaerts<0>(c, fa, st); break;
         case 1: rc = launch_heyvaerts<1>(c, fa, st); break;
@@ -1427,7 +1438,7 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
     return RIMPHONY_OK;
 }
 
-extern "C" int rimphony_last_tail(rimphony_ctx *c, uint64_t out[6])
+extern "C" int rimphony_last_tail(rimphony_ctx *c, uint64_t out[8])
 {
     if (!c || !out) return RIMPHONY_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1437,6 +1448,7 @@ extern "C" int rimphony_last_tail(rimphony_ctx *c, uint64_t out[6])
     out[0] = h[14] >> 24; out[1] = h[14] & 0xffffffull;
     out[2] = h[15] >> 24; out[3] = h[15] & 0xffffffull;
     out[4] = h[8]; out[5] = h[9];
+    out[6] = h[10]; out[7] = h[11];
     return RIMPHONY_OK;
 }
 

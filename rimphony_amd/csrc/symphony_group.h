@@ -41,8 +41,9 @@ namespace rim {
 #define CAP_GOUTER 16
 #endif
 // per-member global spill behind the LDS lists: the GSL limits of the path (symphony.rs:375-380: 5000; :264-269: 1000)
+// (the Faraday group -- heyvaerts_group.h -- uses the same stores: its limits are 4096 / 4096, heyvaerts.rs:82-83)
 #define SPILL_GINNER 5000
-#define SPILL_GOUTER 1000
+#define SPILL_GOUTER 4096
 #define SPILL_GROUP_DOUBLES_PER_WAVE (RIM_GROUP * (RIM_ISTORE_DOUBLES(SPILL_GINNER) + RIM_ISTORE_DOUBLES(SPILL_GOUTER)))
 
 // A member is identified by its output slot 0..5 (lib.rs:176-177): coefficient = slot & 1 (emission, absorption),
@@ -85,13 +86,15 @@ struct GroupMember {
     int snext;                  // replacement cursor
 };
 
-struct GroupPark {
+struct GroupParkBase {
     GroupMember mem[RIM_GROUP];
     WaveCounters ctr;           // samples / inner_qags: summed over members (the reference's counts); steps: passes executed
     unsigned long long member_passes;   // passes a solo run of every member would have executed (sharing = member_passes / steps)
     unsigned long long stash_filed, stash_used;
     unsigned long long *hb;
-    LeungOrder ord[4];          // order records (n, n + 1) of the one or two gamma-integrals in flight
+};
+struct GroupPark : GroupParkBase {
+    LeungOrder ord[4];          // Symphony: order records (n, n + 1) of the one or two gamma-integrals in flight
 };
 
 __device__ __forceinline__ IStore group_store(double *lds_base, int cap, double *spill_base, int gcap, int m)
@@ -198,7 +201,7 @@ __device__ __forceinline__ bool group_book(GroupMember *M, const IStore &st, con
 template <class F>
 __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *inner_lds, double *inner_spill,
                                                double a0, double b0, double a1, double b1, unsigned maskA, unsigned maskB,
-                                               double epsrel, int limit, GroupPark *gp)
+                                               double epsrel, int limit, GroupParkBase *gp)
 {
     const int lane = g.lane;
     const bool have1 = maskB != 0;
@@ -507,7 +510,7 @@ __device__ __forceinline__ void sym_eval_group(const SymPoint &pt, const DistPar
 }
 
 // value and status bits of member m's entry e after sym_eval_group (symphony.rs:375-380: an Err is a NaN sample)
-__device__ __forceinline__ double group_entry_value(const GroupPark *gp, int m, int e, int &st)
+__device__ __forceinline__ double group_entry_value(const GroupParkBase *gp, int m, int e, int &st)
 {
     const int qs = uni(gp->mem[m].qst[e]);
     if (qs != QAG_SUCCESS) {

@@ -7,6 +7,7 @@
 #include "../../rimphony_amd/csrc/heyvaerts_wave.h"
 namespace rim { unsigned long long g_emu_hist[64]; }
 #include "../../rimphony_amd/csrc/symphony_group.h"
+#include "../../rimphony_amd/csrc/heyvaerts_group.h"
 
 using namespace rim;
 
@@ -229,4 +230,78 @@ extern "C" void emu_gk31(const double *fv_nodes, double hl, double *out4)
     for (int i = 0; i < 64; i++) pthread_join(th[i], nullptr);
     pthread_barrier_destroy(&emu_wave().bar);
     for (int k = 0; k < 4; k++) out4[k] = t.out[k];
+}
+
+
+// ---- the Faraday pair (heyvaerts_group.h) on the emulated wave ---------------------------------------------------
+template <int KIND>
+static void hey_group_lane_body(EmuGroupTask *t)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_ginner[RIM_GROUP * RIM_ISTORE_DOUBLES(CAP_GINNER)];
+    __shared__ HeyTask s_park[RIM_GROUP];
+    __shared__ GroupParkBase s_gp;
+    static double s_spill[SPILL_GROUP_DOUBLES_PER_WAVE];
+    const GKLane g = gk_lane_init(s_tab);
+    if (g.lane == 0) { s_gp.ctr = WaveCounters{0, 0, 0}; s_gp.member_passes = 0; s_gp.stash_filed = 0; s_gp.stash_used = 0; s_gp.hb = nullptr; }
+    wv_sync();
+    HeyPoint hp;
+    hp.s = uni(t->s);
+    rim_sincos(t->theta, &hp.sin_th, &hp.cos_th);
+    hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = STOKES_Q;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = t->par[k];
+    dist_prepare<KIND>(d, t->norm);
+    const HeyConsts hc = hey_consts(hey_series_table_host(), hey_series_lds_table_host());
+    double vals[RIM_GROUP] = { 0, 0, 0, 0 };
+    int stats[RIM_GROUP] = { 0, 0, 0, 0 };
+    heyvaerts_group<KIND>(hp, d, hc, t->slots, t->nmem, g, s_ginner, s_spill,
+                          s_spill + RIM_GROUP * RIM_ISTORE_DOUBLES(SPILL_GINNER), s_park, &s_gp, vals, stats);
+    for (int m = 0; m < RIM_GROUP; m++) { t->vals[g.lane][m] = vals[m]; t->stats[g.lane][m] = stats[m]; }
+    wv_sync();
+    if (g.lane == 0) {
+        t->samples = s_gp.ctr.samples; t->passes = s_gp.ctr.steps; t->inner_qags = s_gp.ctr.inner_qags;
+        t->member_passes = s_gp.member_passes; t->stash_filed = s_gp.stash_filed;
+    }
+}
+
+static void *hey_group_thread_main(void *p)
+{
+    ThreadArg *a = (ThreadArg *) p;
+    EmuGroupTask *t = (EmuGroupTask *) (void *) a->t;
+    emu_lane_ref() = a->lane;
+    switch (t->kind) {
+    case 0: hey_group_lane_body<0>(t); break;
+    case 1: hey_group_lane_body<1>(t); break;
+    case 2: hey_group_lane_body<2>(t); break;
+    default: hey_group_lane_body<3>(t); break;
+    }
+    return nullptr;
+}
+
+extern "C" int emu_heyvaerts_group(int kind, unsigned slots, int nmem, double s, double theta, const double *par, double norm,
+                                   double *vals, int *stats, unsigned long long *work4)
+{
+    static EmuGroupTask t;
+    t.kind = kind; t.nmem = nmem; t.slots = slots; t.s = s; t.theta = theta; t.norm = norm;
+    for (int k = 0; k < 5; k++) t.par[k] = par[k];
+    pthread_barrier_init(&emu_wave().bar, nullptr, 64);
+    pthread_t th[64];
+    ThreadArg args[64];
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 1 << 20);
+    for (int i = 0; i < 64; i++) {
+        args[i].t = (EmuTask *) (void *) &t; args[i].lane = i;
+        pthread_create(&th[i], &attr, hey_group_thread_main, &args[i]);
+    }
+    for (int i = 0; i < 64; i++) pthread_join(th[i], nullptr);
+    pthread_barrier_destroy(&emu_wave().bar);
+    int uniform = 1;
+    for (int i = 1; i < 64; i++)
+        for (int m = 0; m < nmem; m++)
+            if (std::memcmp(&t.vals[i][m], &t.vals[0][m], 8) != 0 || t.stats[i][m] != t.stats[0][m]) uniform = 0;
+    for (int m = 0; m < nmem; m++) { vals[m] = t.vals[0][m]; stats[m] = t.stats[0][m]; }
+    work4[0] = t.samples; work4[1] = t.passes; work4[2] = t.inner_qags; work4[3] = t.member_passes; work4[4] = t.stash_filed;
+    return uniform;
 }

@@ -248,6 +248,36 @@ def test_f32_integrand_is_refused_for_the_anisotropic_distributions(gpu_ctx):
         assert np.isfinite(out[:, :6]).any()
 
 
+def test_kernel_variants_change_no_bit(gpu_ctx):
+    """The A/B switches of the library: RIMPHONY_SYM_SOLO=1 (one wave per (point, coefficient), the round-2 Symphony
+    kernel) and RIMPHONY_FARADAY_GROUP=1 (rho_Q and rho_V of a point in lock-step, heyvaerts_group.h -- measured slower,
+    off by default).  Each in a child process (the variables are read when a context is created; the child's context runs
+    in shared mode next to this one): same table and status words, bit for bit, as the default configuration."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from rimphony_amd import api, workload
+ctx = api.Context(0)
+kind, mask, s, th, params = workload.make_batch("cfg4_pitchypl_8", 96)
+out, st = ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+np.save(sys.argv[1], out); np.save(sys.argv[2], st)
+ctx.close()
+''' % ROOT
+    import tempfile
+    kind, mask, s, th, params = workload.make_batch("cfg4_pitchypl_8", 96)
+    ref, ref_st = gpu_ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
+    for var in ("RIMPHONY_SYM_SOLO", "RIMPHONY_FARADAY_GROUP"):
+        with tempfile.TemporaryDirectory() as td:
+            fo, fs = os.path.join(td, "o.npy"), os.path.join(td, "s.npy")
+            env = dict(os.environ, **{var: "1"})
+            r = subprocess.run([sys.executable, "-c", code, fo, fs], capture_output=True, text=True, env=env, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            out, st = np.load(fo), np.load(fs)
+        assert same_bits(out, ref).all(), var
+        assert (st == ref_st).all(), var
+
+
 def test_owner_fallback_changes_no_bit(gpu_ctx):
     """The cooperative tail's last resort: an owner whose helpers do not answer in time closes its batch, evaluates all
     of it itself and never publishes again.  With the bound cut to 1 microsecond (RIMPHONY_OWNER_WAIT_US) nearly every

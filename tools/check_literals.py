@@ -338,14 +338,18 @@ def main():
         return run_chain(body, env)
 
     # non-resonant elements: pure arithmetic
-    nr_dev = between(dh, "RIM_DEV void nr_common(", "template <int KIND>\nRIM_DEV double h_nr_element")
+    nr_dev = between(dh, "RIM_DEV void nr_common(", "// want_h: the")
     nr_dev = nr_dev.replace("x_sq = c.x * c.x", "x_sq = x * x").replace("c.sigma", "sigma").replace("c.x", "x")
     common = run_chain(nr_dev, {"sigma": sig, "x": xx})
-    for fn, stop in (("h_nr_element", "template <int KIND>\nRIM_DEV double f_qr_element"), ("f_nr_element", "// The inner integrand of either regime")):
+    # (round 3: the elements of dev_heyvaerts.h are the branches of hey_member, fed by hey_shared)
+    member = between(dh, "RIM_DEV double hey_member(", "// The inner integrand of either regime")
+    nr_q = member[member.index("const double u3 = u2 * u;"):member.index("const double z =")]
+    nr_q = nr_q[:nr_q.rindex("}")]
+    nr_v = member[member.index("const double z ="):]
+    for fn, body in (("h_nr_element", nr_q), ("f_nr_element", nr_v)):
         ref, _ = run_rust(fn)
-        body = between(dh, "RIM_DEV double %s(" % fn, stop)
-        body = re.sub(r"double a1, a2, xa1p, x_sq, u, u2;\s*nr_common\([^;]*;", "", body)
-        e = run_dev(body + " ", "{", "\n}\n" if "\n}\n" in body else "}", extra={k: common[k] for k in ("a1", "a2", "xa1p", "x_sq", "u", "u2")})
+        body = body.replace("sh.dfds", "dfdsigma()")
+        e = run_dev("X;\n" + body + "\nEND", "X", "END", extra={k: common[k] for k in ("a1", "a2", "xa1p", "x_sq", "u", "u2")})
         same("%s (heyvaerts.rs:379-394 / 453-468)            vs dev_heyvaerts.h" % fn, e["RESULT"], ref)
         body = between(oh, "static double %s(const hey_state *st)" % fn, "\n}\n")
         e = run_dev(body + " ", "{", "return" if False else "\n", extra=None) if False else run_dev(oh, "static double %s(const hey_state *st)" % fn, "\n}\n")
