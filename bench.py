@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=65536, help="table rows per GPU per step")
+    ap.add_argument("--points", type=int, default=131072, help="table rows per GPU per step")
     ap.add_argument("--config", default="cfg2_powerlaw_8")
     ap.add_argument("--cpu-sample", type=int, default=256,
                     help="rows of the all-cores eight-coefficient CPU baseline (the other three are scaled from it; 0 = skip)")

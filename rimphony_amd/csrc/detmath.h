@@ -518,10 +518,11 @@ RIM_FN void rim_meissel_roots(double y, double *Z, double *inv_z3, double *inv_s
  * pitchy_kappa.rs:66-70 write powf(..) * exp(..)).  Within an ulp of the product of the two correctly rounded factors
  * and a third cheaper than rim_pow_normal(x, y) * rim_exp(e); where the separate factors would over- or underflow
  * on their own and the product not, this returns the product.  Oracle (deterministic build) and kernels share it. */
-RIM_FN double rim_powexp_normal(double x, double y, double e)
+/* ... its two halves: the double-double logarithm of x, and everything after it.  rim_powexp_normal(x, y, e) ==
+ * rim_powexp_from_log(lh, ll, y, e) with (lh, ll) = rim_log_dd_normal(x): the same operations, the same bits -- for callers
+ * that need x^y1 e^e and x^y2 e^e of one x (the emission and absorption terms of one sample, symphony_group.h). */
+RIM_FN double rim_powexp_from_log(double lh, double ll, double y, double e)
 {
-    double ll;
-    const double lh = rim_log_dd_normal(x, &ll);
     const double ph = y * lh;
     const double pl = rim_fma(y, lh, -ph) + y * ll;
     const double s = ph + e;                      /* two-sum of ph and e */
@@ -530,6 +531,13 @@ RIM_FN double rim_powexp_normal(double x, double y, double e)
     if (s > 709.782712893384) return RIM_INF;
     if (s < -745.2) return 0.0;
     return rim_exp_dd_core(s, sl);
+}
+
+RIM_FN double rim_powexp_normal(double x, double y, double e)
+{
+    double ll;
+    const double lh = rim_log_dd_normal(x, &ll);
+    return rim_powexp_from_log(lh, ll, y, e);
 }
 
 /* x^(1/3) for a positive normal finite x, < 1 ulp (tests/test_detmath.py), in 22 operations where the general power

@@ -296,6 +296,69 @@ RIM_DEV double gamma_integrand_f_term(int coeff, const DistParams &d, double cos
     return dfdg + dfdcx_factor * dfdcx;
 }
 
+// calc_f AND calc_f_derivatives of one sample (the emission and absorption members of a group, symphony_group.h): the
+// values calc_f / calc_f_derivatives return, bit for bit, with what the two have in common computed once -- the
+// double-double logarithm of gamma of the power-law energy factor (rim_powexp_from_log), the exponential of the thermal
+// distribution, and for the anisotropic distributions f itself, which calc_f_derivatives forms by calc_f's own expression
+// (pitchy_pl.rs:56-61, pitchy_kappa.rs:53-58).
+template <int KIND>
+RIM_DEV void calc_f_both(const DistParams &d, double gamma, double cos_xi, double &f, double &dfdg, double &dfdcx)
+{
+    if (KIND == DIST_POWER_LAW) {
+        f = 0.; dfdg = 0.; dfdcx = 0.;
+        if (gamma < d.par[1] || gamma > d.par[2]) return;
+        RIM_HIT(19); RIM_HIT(20);
+        double ll;
+        const double lh = rim_log_dd_normal(gamma, &ll);
+        const double e = -gamma * d.inv_gamma_cutoff;
+        const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
+        f = d.norm * rim_powexp_from_log(lh, ll, -d.par[0], e) / (gamma * gamma * beta);
+        const double p_plus_1 = d.par[0] + 1.;
+        const double g2_minus_1 = gamma * gamma - 1.;
+        dfdg = -d.norm * rim_powexp_from_log(lh, ll, -p_plus_1, e) / rim_sqrt(g2_minus_1) *
+            (p_plus_1 / gamma + gamma / g2_minus_1 + d.inv_gamma_cutoff);
+    } else if (KIND == DIST_THERMAL_JUETTNER) {
+        f = d.norm * RimMath<0>::exp(d.neg_inverse_t * gamma);
+        dfdg = f * d.neg_inverse_t;
+        dfdcx = 0.;
+    } else if (KIND == DIST_PITCHY_PL) {
+        f = 0.; dfdg = 0.; dfdcx = 0.;
+        if (gamma < d.par[2] || gamma > d.par[3]) return;
+        const double p = d.par[0], k = d.par[1];
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = RimMath<0>::pow(sin_xi, k);
+        const double beta = rim_sqrt(1. - rim_div_moderate(1., gamma * gamma));
+        const double gamma_term = RimMath<0>::powexp_normal(gamma, -p, -gamma * d.inv_gamma_cutoff);
+        f = d.norm * pa_term * gamma_term / (gamma * gamma * beta);
+        dfdg = -f * ((p + 1.) / gamma + gamma / (gamma * gamma - 1.) + d.inv_gamma_cutoff);
+        dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
+    } else {
+        const double kappa = d.par[0], width = d.par[1], k = d.par[2];
+        const double sin_xi = rim_sqrt(1. - cos_xi * cos_xi);
+        const double pa_term = RimMath<0>::pow(sin_xi, k);
+        const double gamma_term = kappa_gamma_term<0>(d, gamma);
+        f = d.norm * pa_term * gamma_term;
+        dfdg = -f * ((kappa + 1.) / (kappa * width + gamma - 1.) + d.inv_gamma_cutoff);
+        dfdcx = -f * k * cos_xi / (sin_xi * sin_xi);
+    }
+}
+
+// the emission and the absorption f_term of one sample (symphony.rs:455-463) from calc_f_both
+template <int KIND>
+RIM_DEV void gamma_integrand_f_terms(const DistParams &d, double cos_th, const GiShared &sh, double &f_em, double &f_ab)
+{
+    const double gamma = sh.gamma, beta = sh.beta, cos_xi = sh.cos_xi;
+    double dfdg, dfdcx;
+    RIM_HIT(24); RIM_HIT(25);
+    calc_f_both<KIND>(d, gamma, cos_xi, f_em, dfdg, dfdcx);
+    if (KIND == DIST_POWER_LAW || KIND == DIST_THERMAL_JUETTNER) {
+        f_ab = dfdg + ((beta * cos_th - cos_xi) * dfdcx) * (gamma - 1.);       // (gamma_integrand_f_term says why)
+    } else {
+        const double dfdcx_factor = (beta * cos_th - cos_xi) / (gamma - 1. / gamma);
+        f_ab = dfdg + dfdcx_factor * dfdcx;
+    }
+}
+
 template <int KIND, int PREC = 0>
 RIM_DEV double gamma_integrand(const SymPoint &pt, const DistParams &d, const SymOrder &so, double gamma)
 {

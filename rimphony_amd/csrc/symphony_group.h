@@ -459,8 +459,14 @@ struct SymGroupF {
             sh = gamma_integrand_shared<0>(s, cos_th, sin_th, so, x);
             RIM_PROF_T(t_f);
             g2 = x * x;
-            if (need_em) f_em = gamma_integrand_f_term<KIND, 0>(COEFF_EMISSION, *d, cos_th, sh);
-            if (need_ab) f_ab = gamma_integrand_f_term<KIND, 0>(COEFF_ABSORPTION, *d, cos_th, sh);
+#if !defined(RIM_NO_FTERM_SHARE)           // (A/B knob of tools/build_variant.sh)
+            if (need_em && need_ab) gamma_integrand_f_terms<KIND>(*d, cos_th, sh, f_em, f_ab);     // what the two share, once
+            else
+#endif
+            {
+                if (need_em) f_em = gamma_integrand_f_term<KIND, 0>(COEFF_EMISSION, *d, cos_th, sh);
+                if (need_ab) f_ab = gamma_integrand_f_term<KIND, 0>(COEFF_ABSORPTION, *d, cos_th, sh);
+            }
             RIM_PROF_ADD(6, t_f);
         }
     }
