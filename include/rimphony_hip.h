@@ -163,7 +163,8 @@ int rimphony_last_faraday_ms(rimphony_ctx *ctx, float *ms);
  * [2] phase, [3] integrand passes, [4] inner QAG iteration, [5] chunks,
  * [6] n_start bits, [7] delta_n bits, [8] lane of the running gamma-integral,
  * [9] its n (bits), [10] 1 when the task has finished.  Tasks of the Heyvaerts kernel
- * are addressed as task | (1 << 62). */
+ * are addressed as task | (1 << 62).  Symphony tasks are watched in the one-wave-per-coefficient kernel only
+ * (RIMPHONY_SYM_SOLO=1 when the context is created); the group kernel does not write heartbeats. */
 int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_words);
 
 /* Diagnostics: the 16 raw device counter words of the most recent batch call: [0] task head,
@@ -278,6 +279,14 @@ int rimphony_highfreq_batch(rimphony_ctx *ctx, int dist_kind, size_t n, const do
 int rimphony_n_integral_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params,
                                      int coeff, int stokes, int negative_lobe, double s, double theta,
                                      size_t count, const double *d_n_lo, const double *d_n_hi, double *d_out, void *stream);
+
+/* Unit seam for gsl::deriv_central (gsl.rs:233-257 -> gsl_deriv_central: 5-point central difference with one step-size
+ * refinement) as n_integration drives it (symphony.rs:238-240): d_out[i] = the accepted derivative estimate of the
+ * gamma-integral with respect to the harmonic number at d_n_start[i], step h = 1e-10 n_start, computed by the
+ * derivative-probe phases of the coefficient's state machine (the code the product kernels run). */
+int rimphony_deriv_probe_batch_device(rimphony_ctx *ctx, int dist_kind, const double *params,
+                                      int coeff, int stokes, int negative_lobe, double s, double theta,
+                                      size_t count, const double *d_n_start, double *d_out, void *stream);
 
 /* Diagnostic seam: diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567), the
  * contribution of all harmonics at fixed gamma (cgs-scaled like a coefficient), for one parameter point. */

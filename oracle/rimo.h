@@ -139,6 +139,8 @@ double rimo_gamma_contribution(const rimo_dist *d, int coeff, int stokes, double
 int rimo_n_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta,
                     double n_lo, double n_hi, double *value);
 double rimo_gamma_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta, double n);
+/* gsl::deriv_central as n_integration calls it (symphony.rs:238-240): d(gamma_integral)/dn at n_start, h = 1e-10 n_start */
+double rimo_symphony_deriv_probe(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta, double n_start);
 
 /* batch: N x (full_calculation + selected coefficients); params SoA [nparams][n];
  * out [n][8] row-major in the order of lib.rs:176-177; counters may be NULL

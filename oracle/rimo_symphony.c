@@ -354,6 +354,19 @@ int rimo_n_integral(const rimo_dist *d, int coeff, int stokes, int negative_lobe
     return status;
 }
 
+/* unit seam for gsl::deriv_central as n_integration calls it (symphony.rs:238-240): the derivative estimate of the
+ * gamma-integral with respect to n at n_start, h = 1e-10 n_start */
+double rimo_symphony_deriv_probe(const rimo_dist *d, int coeff, int stokes, int negative_lobe, double s, double theta, double n_start)
+{
+    sym_state st;
+    double deriv = 0., derr = 0.;
+    sym_init(&st, d, coeff, stokes, s, theta, NULL);
+    st.negative_lobe = negative_lobe;
+    rimo_deriv_central(gamma_integral_cb, &st, n_start, 1e-10 * n_start, &deriv, &derr);
+    rimo_workspace_free(st.gamma_ws);
+    return deriv;
+}
+
 /* diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567): the contribution of all
  * harmonics n at fixed gamma -- the Symphony double integral with the order of integration reversed. */
 typedef struct { sym_state *st; double gamma; } contrib_ctx;

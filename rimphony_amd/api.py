@@ -301,6 +301,18 @@ class Context:
         torch.cuda.synchronize(self._dev())
         return out.cpu().numpy()
 
+    def deriv_probe_batch(self, kind, params, coeff, stokes, negative_lobe, s, theta, n_start):
+        """gsl::deriv_central as n_integration drives it (symphony.rs:238-240): d(gamma_integral)/dn at each n_start."""
+        dn = self._as_dev(n_start)
+        out = torch.empty_like(dn)
+        par = (ctypes.c_double * len(params))(*params)
+        capi.check(self.lib.rimphony_deriv_probe_batch_device(
+            self.handle, kind, par, int(coeff), int(stokes), int(negative_lobe), s, theta, dn.numel(),
+            ctypes.c_void_p(dn.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()),
+            "rimphony_deriv_probe_batch_device")
+        torch.cuda.synchronize(self._dev())
+        return out.cpu().numpy()
+
     def gamma_contribution_batch(self, kind, params, coeff, stokes, s, theta, gamma):
         """diagnostic_symphony_gamma_contribution over an array of gammas of one parameter point."""
         dg = self._as_dev(gamma)

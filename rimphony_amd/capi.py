@@ -17,7 +17,7 @@ SYMBOLS = [
     "rimphony_gamma_integral_batch_device", "rimphony_n_integral_batch_device", "rimphony_gamma_contribution_batch_device", "rimphony_calc_f_batch_device", "rimphony_calc_f_batch", "rimphony_qag_selftest_device", "rimphony_highfreq_batch_device", "rimphony_highfreq_batch", "rimphony_detmath_batch_device", "pkgw_bessel_j", "pkgw_bessel_dj",
     "rimphony_ctx_shared_mode", "rimphony_last_error", "rimphony_batch_compute_device_ex", "rimphony_batch_compute_ex",
     "rimphony_batch_compute_multi", "rimphony_status_histogram_device",
-    "rimphony_hey_element_batch_device", "rimphony_hey_outer_batch_device", "rimphony_last_tail",
+    "rimphony_hey_element_batch_device", "rimphony_hey_outer_batch_device", "rimphony_last_tail", "rimphony_deriv_probe_batch_device",
 ]
 
 
@@ -105,6 +105,9 @@ def load():
                                                  c_void_p]
     lib.rimphony_ctx_shared_mode.restype = c_int
     lib.rimphony_ctx_shared_mode.argtypes = [c_void_p]
+    lib.rimphony_deriv_probe_batch_device.restype = c_int
+    lib.rimphony_deriv_probe_batch_device.argtypes = [c_void_p, c_int, dp, c_int, c_int, c_int, c_double, c_double, c_size_t,
+                                                      c_void_p, c_void_p, c_void_p]
     lib.rimphony_last_tail.restype = c_int
     lib.rimphony_last_tail.argtypes = [c_void_p, POINTER(c_uint64)]
     lib.rimphony_last_error.restype = c_char_p

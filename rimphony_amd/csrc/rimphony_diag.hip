@@ -66,6 +66,64 @@ __global__ __launch_bounds__(64) void n_integral_kernel(PointArgs pa, const doub
     }
 }
 
+// Unit seam for gsl::deriv_central (gsl.rs:233-257 -> gsl_deriv_central) as n_integration drives it
+// (symphony.rs:238-240): the derivative of the gamma-integral with respect to the harmonic number at n_start[i], step
+// h = 1e-10 n_start.  One wave per abscissa runs the PH_DERIV1 (and, if the first estimate asks for it, PH_DERIV2) phases
+// of the coefficient's state machine -- the code the product kernels run -- and reports dr_r0, the accepted estimate.
+template <int KIND>
+__global__ __launch_bounds__(64) void deriv_probe_kernel(PointArgs pa, const double *norm_ptr, size_t count,
+                                                         const double *n_start, double *out, double *spill_base)
+{
+    __shared__ double s_tab[96];
+    __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
+    __shared__ double s_outer[RIM_ISTORE_DOUBLES(CAP_OUTER)];
+    __shared__ TaskState s_park;
+    const GKLane g = gk_lane_init(s_tab);
+    double *spill = spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE;
+    const IStore inner = istore_carve(s_inner, CAP_INNER, spill, SPILL_INNER);
+    const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
+    __shared__ QagPark s_qpark;
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
+    SymPoint pt;
+    pt.s = pa.s;
+    rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
+    pt.coeff = pa.coeff;
+    pt.stokes = pa.stokes;
+    DistParams d;
+    for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
+    dist_prepare<KIND>(d, norm_ptr[0]);
+    for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
+        TaskState T;
+        sym_begin(pt, T);
+        sym_start_lobe(pt, T, pa.negative_lobe);
+        T.n_start = uni(n_start[i]);
+        T.dr_h = 1e-10 * T.n_start;
+        T.phase = PH_DERIV1;
+        while (T.phase == PH_DERIV1 || T.phase == PH_DERIV2) {
+            SymBatch B;
+            if (!sym_post(pt, g, outer, T, B)) break;
+            __syncthreads();
+            if (g.lane == 0) s_park = T;
+            int batch_status = 0;
+            double gval = 0.;
+            unsigned long long mask = wv_ballot(B.req_active);
+            while (mask) {
+                const int k = __builtin_ffsll((long long) mask) - 1;
+                mask &= mask - 1;
+                const double n = readlane_d(B.req_n, k);
+                const int lb = wv_readlane(B.req_lobe, k);
+                const double val = sym_eval_request<KIND>(pt, d, g, inner, &s_qpark, n, lb, batch_status);
+                if (g.lane == k) gval = val;
+            }
+            __syncthreads();
+            T = s_park;
+            task_uniformize(T);
+            sym_consume(pt, g, outer, T, B, gval, uni(batch_status));
+        }
+        if (g.lane == 0) out[i] = T.dr_r0;
+    }
+}
+
 // diagnostic_symphony_gamma_contribution (lib.rs:288-296 -> symphony.rs:491-567): all harmonics n at fixed gamma.
 // One wave per gamma; the integrand is sampled in n, so every lane carries its own order data (registers/scratch,
 // as in integrand_kernel_n).  Discrete sums are accumulated by lane 0 in the reference's order.
@@ -156,6 +214,33 @@ extern "C" int rimphony_n_integral_batch_device(rimphony_ctx *c, int kind, const
     case 1: hipLaunchKernelGGL(n_integral_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_lo, d_n_hi, d_out, spill); break;
     case 2: hipLaunchKernelGGL(n_integral_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_lo, d_n_hi, d_out, spill); break;
     default: hipLaunchKernelGGL(n_integral_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_lo, d_n_hi, d_out, spill); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RIMPHONY_OK;
+}
+
+extern "C" int rimphony_deriv_probe_batch_device(rimphony_ctx *c, int kind, const double *params,
+                                                 int coeff, int stokes, int negative_lobe, double s, double theta,
+                                                 size_t count, const double *d_n_start, double *d_out, void *stream)
+{
+    if (!c || (count && (!d_n_start || !d_out))) return RIMPHONY_EINVAL;
+    hipStream_t st = (hipStream_t) stream;
+    RimCtxScope scope(c, st);          // the context's lock + ordering behind earlier work on its workspace
+    { const int rc0 = scope.enter(); if (rc0) return rc0; }
+    PointArgs pa;
+    int rc = rim_point_setup(c, kind, params, coeff, stokes, negative_lobe, s, theta, st, pa);
+    if (rc) return rc;
+    if (count == 0) return RIMPHONY_OK;
+    unsigned grid = 0;
+    rc = rim_wave_grid(c, count, 16, &grid);
+    if (rc) return rc;
+    const double *norm = rim_ctx_norm(c);
+    double *spill = rim_ctx_spill(c);
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(deriv_probe_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_start, d_out, spill); break;
+    case 1: hipLaunchKernelGGL(deriv_probe_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_start, d_out, spill); break;
+    case 2: hipLaunchKernelGGL(deriv_probe_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_start, d_out, spill); break;
+    default: hipLaunchKernelGGL(deriv_probe_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, count, d_n_start, d_out, spill); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;

@@ -30,9 +30,44 @@ def oracle_libm():
     return oracle_bind.load("libm")
 
 
+class _ContextProxy:
+    """The session's GPU context, created on first use.  A test that needs the device for a child process (the first
+    context on a device owns it: cooperative tail, full grids) asks for it with `with gpu_ctx.released():`; the context
+    is closed for the duration and the NEXT use -- in this or any later test -- opens a fresh one.  No test depends on
+    another one's clean-up."""
+
+    def __init__(self):
+        self._ctx = None
+
+    def _get(self):
+        if self._ctx is None:
+            from rimphony_amd import api
+            self._ctx = api.Context(0)
+        return self._ctx
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def released(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.close_now()
+            try:
+                yield
+            finally:
+                self.close_now()          # whatever the body opened through the proxy does not outlive it either
+        return cm()
+
+    def close_now(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
-    from rimphony_amd import api
-    ctx = api.Context(0)
-    yield ctx
-    ctx.close()
+    proxy = _ContextProxy()
+    yield proxy
+    proxy.close_now()

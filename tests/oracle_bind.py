@@ -53,6 +53,8 @@ def load(flavour="det"):
     L.rimo_gamma_integrand.argtypes = [POINTER(Dist), c_int, c_int, c_double, c_double, c_double, c_double]
     L.rimo_gamma_integral.restype = c_double
     L.rimo_gamma_integral.argtypes = [POINTER(Dist), c_int, c_int, c_int, c_double, c_double, c_double]
+    L.rimo_symphony_deriv_probe.restype = c_double
+    L.rimo_symphony_deriv_probe.argtypes = [POINTER(Dist), c_int, c_int, c_int, c_double, c_double, c_double]
     L.rimo_batch.restype = c_int
     L.rimo_batch.argtypes = [c_int, c_size_t, dp, dp, POINTER(dp), c_uint32, dp, POINTER(Counters), c_int]
     L.rimo_batch_norm.restype = c_int

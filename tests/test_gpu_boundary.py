@@ -296,8 +296,7 @@ np.save(sys.argv[1], out); np.save(sys.argv[2], st)
 print("shared" if ctx.shared_mode() else "exclusive")
 ''' % ROOT
     import tempfile
-    gpu_ctx.close()                 # release the device lock: the children must own the GPU to use the cooperative tail
-    try:
+    with gpu_ctx.released():        # the children must own the GPU to use the cooperative tail (tests/conftest.py)
         with tempfile.TemporaryDirectory() as d:
             res = {}
             for name, env_extra in (("normal", {}), ("impatient", {"RIMPHONY_OWNER_WAIT_US": "1"})):
@@ -309,6 +308,3 @@ print("shared" if ctx.shared_mode() else "exclusive")
                 res[name] = (np.load(o), np.load(s_))
             assert same_bits(res["normal"][0], res["impatient"][0]).all()
             assert (res["normal"][1] == res["impatient"][1]).all()
-    finally:
-        # give the session fixture a live context back
-        gpu_ctx.__init__(0)

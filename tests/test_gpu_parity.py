@@ -587,6 +587,26 @@ def test_n_integral_diagnostic_bit_exact(gpu_ctx, oracle):
         assert np.isfinite(ref).sum() > 12
 
 
+def test_deriv_central_seam_bit_exact(gpu_ctx, oracle):
+    """gsl::deriv_central (gsl.rs:233-257 -> gsl_deriv_central: central_deriv with h, then the optimal-step refinement) as
+    n_integration drives it (symphony.rs:238-240): the derivative-probe phases of the state machine against the oracle's
+    rimo_deriv_central on the oracle's gamma-integral, bit for bit.  The inputs include abscissae where the refinement is
+    taken (round-off below truncation error) and where it is not."""
+    rng = np.random.default_rng(33)
+    cases = ((0, [2.8, 1.0, 1e12, 1e10], 30., 0.9), (1, [8.0], 200., 0.6), (3, [3.0, 5.0, 1.5, 1e10], 12., 1.2))
+    for kind, params, s, th in cases:
+        d, st = oracle_bind.mkdist(oracle, kind, params)
+        assert st == 0
+        n_minus = s * math.sin(th)
+        n0 = np.floor(n_minus + 31. + rng.uniform(0., 400., 20))
+        n0[10:] = n0[10:] * rng.uniform(1.5, 40., 10)          # non-integer starts further out in the tail
+        for coeff, stokes, lobe in ((0, 0, 0), (1, 1, 0), (0, 2, 1)):
+            got = gpu_ctx.deriv_probe_batch(kind, params, coeff, stokes, lobe, s, th, n0)
+            ref = np.array([oracle.rimo_symphony_deriv_probe(ctypes.byref(d), coeff, stokes, lobe, s, th, float(x)) for x in n0])
+            report_mismatch("deriv_central", got, ref, lambda i: (kind, coeff, stokes, n0[i]))
+            assert np.isfinite(ref).sum() >= 10
+
+
 def test_gamma_contribution_diagnostic_bit_exact(gpu_ctx, oracle):
     """diagnostic_symphony_gamma_contribution (lib.rs:288-296): fully discrete sums (few harmonics) and the
     31-discrete + QAG-over-n branch (more than 1000 harmonics)."""

@@ -25,5 +25,10 @@ for d in dirs:
                 if "Heyvaerts" not in r["kernel"]:
                     r["work"] = {"kernel_ms_under_pmc": float(m.group(1)), "samples": int(m.group(2)), "passes": int(m.group(3)), "inner_qags": int(m.group(4))}
         break
+# the build the counters were taken on: bench.py only quotes them for that build
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rimphony_amd import _build
+for r in res:
+    r["source_id"] = _build.source_id()
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
