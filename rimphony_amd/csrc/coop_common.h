@@ -100,6 +100,7 @@ struct AssistSlot {
     unsigned long long res[64];
     int req_lobe[64];
     int res_status[64];
+    unsigned res_samples[64];         // integrand samples the request took (booked by the owner when it reads the value)
 };
 
 // Board payload accessors: relaxed agent-scope atomics = sc1 (write-through / L1-bypassing) stores

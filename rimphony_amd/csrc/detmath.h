@@ -32,7 +32,14 @@
  * -DRIM_PROF -DRIM_PROF_COUNTS turns the timers off and counts instead how often a wave enters the places marked
  * RIM_HIT(idx) (counted by the first ACTIVE lane, so a branch that any lane takes counts once per wave):
  * execution frequencies to weight the static instruction counts of tools/isa_mix.py with. */
-#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(RIM_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+/* -DRIM_ISA_MARKS (hipcc -S only): the region timers become comments in the listing, for tools/isa_regions.py */
+#define RIM_PROF_T(t) asm volatile("; REGION_BEGIN " #t)
+#define RIM_PROF_ADD(idx, t) asm volatile("; REGION_END " #t)
+#define RIM_PROF_COUNT(idx, v)
+#define RIM_HIT(idx)
+#define RIM_LANES(idx, cond)
+#elif defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
 extern __shared__ unsigned long long rim_prof_lds[];      /* 32 words of dynamic LDS per workgroup */
 #if defined(RIM_PROF_COUNTS)
 #define RIM_PROF_T(t)

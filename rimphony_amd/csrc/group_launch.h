@@ -39,6 +39,7 @@ struct GroupArgs {
     GroupSlot *gboard;              // [gridDim.x]
     double *gspill;                 // [gridDim.x][SPILL_GROUP_DOUBLES_PER_WAVE]
     int coop;                       // cooperative tail on
+    unsigned long long *prof;       // -DRIM_PROF builds: [gridDim.x][32] region timers / hit counters (else null)
 };
 
 // faraday = 0: the Symphony groups ({j_I, alpha_I, j_Q, alpha_Q}, {j_V, alpha_V}); 1: the Faraday pair {rho_Q, rho_V}

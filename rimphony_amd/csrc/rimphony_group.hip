@@ -141,6 +141,11 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
         s_gp.member_passes = 0; s_gp.stash_filed = 0; s_gp.stash_used = 0;
         s_gp.hb = nullptr;
     }
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x < 32) rim_prof_lds[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    RIM_PROF_T(t_kernel);
 
     GroupSlot *const my = ga.gboard + blockIdx.x;
     unsigned *const flag_exhausted = a.board_flags + BOARD_FLAG_EXHAUSTED;
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 continue;
             }
             // the members that are furthest behind post their batches (symphony_group.h: group_turn)
+            RIM_PROF_T(t_post);
             const unsigned turn = P::turn(s_park, alive);
             for (unsigned rem = turn; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
@@ -267,6 +273,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 if (B.req_active) act |= 1u << m;
             }
             __syncthreads();
+            RIM_PROF_ADD(24, t_post);
             if (!posted) continue;
             gc = group_classify(act, rq0, rq1, rq2, rq3, rl0, rl1, rl2, rl3);
             {
@@ -433,7 +440,9 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 if (ek0 < 0) break;
             }
             got += 1;
+            RIM_PROF_T(t_req);
             P::eval(cx, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
+            RIM_PROF_ADD(9, t_req);
             if (shared) {
                 // hand the members' values, status bits and sample counts back through the board
                 if (lane == 0) {
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
         }
         __syncthreads();
         // ---------- every member that posted consumes its results ----------
+        RIM_PROF_T(t_cons);
         for (unsigned rem = posted; rem; rem &= rem - 1) {
             const int m = __builtin_ctz(rem);
             const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
@@ -555,9 +565,14 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
             if (P::done(T)) alive &= ~(1u << m);
         }
         __syncthreads();
+        RIM_PROF_ADD(26, t_cons);
     }
 
+    RIM_PROF_ADD(0, t_kernel);
     __syncthreads();
+#if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (ga.prof && threadIdx.x < 32) ga.prof[(size_t) blockIdx.x * 32 + threadIdx.x] += rim_prof_lds[threadIdx.x];
+#endif
     if (g.lane == 0) {
         atomicAdd(queue + 1, s_gp.ctr.samples);
         atomicAdd(queue + 2, s_gp.ctr.steps);

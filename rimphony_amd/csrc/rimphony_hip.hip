@@ -428,8 +428,6 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         bool ctx_loaded = !helper;
         unsigned long long local_mask = mask;
         int got = 0;
-        size_t work_i = own_i;             // the task the evaluated requests belong to (per-slot work counters)
-        int work_slot = own_slot;
         bool redo;
         do {
         redo = false;
@@ -452,8 +450,6 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     const size_t hi = (size_t) bcast_u64(bget(&src->point));
                     const int hs = __builtin_amdgcn_readfirstlane(bget(&src->slot));
                     P::load(a, hi, hs, cx, norm);
-                    work_i = hi;
-                    work_slot = hs;
                     ctx_loaded = true;
                     if (counted_idle) {
                         if (lane == 0) __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -490,14 +486,20 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             unsigned long long samples_before = 0;
             if (a.work && lane == 0) samples_before = s_qpark.ctr.samples;
             P::eval2(cx, g, inner, &s_qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
-            if (a.work && lane == 0)
-                atomicAdd(a.work + work_i * 8 + (size_t) work_slot, s_qpark.ctr.samples - samples_before);
+            // Work counters count what went INTO the stored value: a request evaluated for the board is booked by
+            // the owner when it reads the result, so a batch the owner gives up on and evaluates again is counted once.
+            unsigned long long samples_taken = 0;
+            if (a.work && lane == 0) {
+                samples_taken = s_qpark.ctr.samples - samples_before;
+                if (!shared) atomicAdd(a.work + own_i * 8 + (size_t) own_slot, samples_taken);
+            }
             RIM_PROF_ADD(9, t_req);
             COOP_DIAG(eval_ticks += wall_clock64() - e0;)
             if (shared) {
                 if (lane == 0) {
                     bput(&src->res[k], rim_bits(val));
                     bput(&src->res_status[k], st);
+                    if (a.work) bput(&src->res_samples[k], (unsigned) samples_taken);
                     drain_vmem();
                     __hip_atomic_fetch_add(&src->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -531,7 +533,11 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 __hip_atomic_store(&my->claim, (unsigned long long) seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (complete) {
                 int stl = 0;
-                if ((mask >> lane) & 1ull) { gval = rim_frombits(bget(&my->res[rank])); stl = bget(&my->res_status[rank]); }
+                if ((mask >> lane) & 1ull) {
+                    gval = rim_frombits(bget(&my->res[rank]));
+                    stl = bget(&my->res_status[rank]);
+                    if (a.work) atomicAdd(a.work + own_i * 8 + (size_t) own_slot, (unsigned long long) bget(&my->res_samples[rank]));
+                }
                 if (wv_ballot((stl & ST_INNER_FAIL) != 0)) batch_status |= ST_INNER_FAIL;
                 if (wv_ballot((stl & ST_STORE_FULL) != 0)) batch_status |= ST_STORE_FULL;
             } else {
@@ -1204,6 +1210,10 @@ static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t co
     ga.gspill = c->d_gspill;
     ga.gboard = c->d_gboard;
     ga.coop = c->no_assist ? 0 : 1;
+    ga.prof = nullptr;
+#if defined(RIM_PROF)
+    if (grid <= RIM_PROF_ROWS) HIP_TRY(hipGetSymbolAddress((void **) &ga.prof, HIP_SYMBOL(g_rim_prof)));
+#endif
     ga.base.board = nullptr;
     ga.base.board_flags = (unsigned *) (c->d_gboard + c->gboard_slots);
     ga.base.idle_ticks = 2ull * c->ticks_per_s;

@@ -204,6 +204,12 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                                                double epsrel, int limit, GroupParkBase *gp)
 {
     const int lane = g.lane;
+    // The masks, limits and tolerances are wave-uniform by construction; saying so keeps the member loops below -- their
+    // masks, member indices, list addresses and counters -- in scalar registers (the compiler cannot see it through the
+    // board path of the caller and otherwise runs all of it on the vector unit, spilling to scratch).
+    maskA = uni(maskA); maskB = uni(maskB);
+    epsrel = uni(epsrel); limit = uni(limit);
+    a0 = uni(a0); b0 = uni(b0); a1 = uni(a1); b1 = uni(b1);
     const bool have1 = maskB != 0;
     unsigned n_pass = 0, n_member_pass = 0, n_samp_all = 0, n_qags = 0, n_filed = 0, n_used = 0;
     int cur = -1;                       // -1: the joint first rule application; then integral 0 (A) and 1 (B)
@@ -230,6 +236,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
             // every member whose list changed picks its next interval; a pick whose children's sums are on file in the
             // member's stash is booked at once
             wv_sync();                  // list entries and member records written in the last turn are visible
+            RIM_PROF_T(t_picks);
             for (unsigned rem = need_pick; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
                 GroupMember *const M = gp->mem + m;
@@ -246,6 +253,8 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
             }
             if (need_pick) wv_sync();
             need_pick = 0;
+            RIM_PROF_ADD(18, t_picks);
+            RIM_PROF_T(t_prep);
             if (!from_stash) {
                 // a pass: the interval of the first active member; it serves the members that picked this interval and
                 // the members that hold it as an entry of their list (their sums go to the stash)
@@ -286,6 +295,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                 active_lane = g.node;
                 second = cur != 0;
             }
+            RIM_PROF_ADD(19, t_prep);
         }
 
         if (serve) {
@@ -306,7 +316,9 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                 GroupMember *const M = gp->mem + m;
                 const bool inA = ((maskA >> m) & 1u) != 0, inB = ((maskB >> m) & 1u) != 0;
                 const bool act_m = cur < 0 ? (g.node && (g.half == 0 ? inA : inB)) : g.node;
+                RIM_PROF_T(t_mem);
                 const double fv = f.member(m, act_m);
+                RIM_PROF_ADD(20, t_mem);
                 RIM_PROF_T(t_gk);
                 const GKRes r = wave_gk31(fv, hl, g);
                 RIM_PROF_ADD(11, t_gk);
@@ -335,6 +347,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                         RIM_PROF_ADD(12, t_ab);
                     } else {
                         // file the children's sums in the member's stash (a free place, else the next one in turn)
+                        RIM_PROF_T(t_file);
                         const int idx = sel4(m, idx0, idx1, idx2, idx3);
                         const unsigned long long freep = wv_ballot(lane < RIM_STASH && M->sk[lane & (RIM_STASH - 1)] < 0);
                         const int pos = freep ? __builtin_ffsll((long long) freep) - 1 : uni(M->snext);
@@ -348,6 +361,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                         if (lane == 32) { M->sr2[pos] = r.result; M->se2[pos] = r.abserr; }
                         stashed |= 1u << m;
                         n_filed += 1;
+                        RIM_PROF_ADD(21, t_file);
                     }
                 }
             }
@@ -355,6 +369,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
 
         if (from_stash) {
             // ---- members whose pick has its children's sums on file: qag.c's loop body without a pass ----
+            RIM_PROF_T(t_fs);
             for (unsigned rem = from_stash; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
                 GroupMember *const M = gp->mem + m;
@@ -373,9 +388,11 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                 n_used += 1;
                 if (fin) active &= ~(1u << m); else need_pick |= 1u << m;
             }
+            RIM_PROF_ADD(22, t_fs);
         }
 
         // ---- the next integral, once the current one has no unfinished member ----
+        RIM_PROF_T(t_next);
         while (cur < 0 || !active) {
             cur += 1;
             if (cur > (have1 ? 1 : 0)) break;
@@ -415,6 +432,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
             }
             need_pick = active;
         }
+        RIM_PROF_ADD(23, t_next);
         if (cur > (have1 ? 1 : 0)) break;
     }
     if (lane == 0) {

@@ -156,6 +156,7 @@ __device__ __forceinline__ double uni(double v)
     return rim_frombits(((unsigned long long) hi << 32) | lo);
 }
 __device__ __forceinline__ int uni(int v) { return wv_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned) wv_readfirstlane((int) v); }
 __device__ __forceinline__ bool uni(bool v) { return wv_readfirstlane((int) v) != 0; }
 
 // The rule sums: v + (value of the other node of the pair) is qk.c's f1 + f2 ...

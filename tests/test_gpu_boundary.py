@@ -282,7 +282,7 @@ def test_owner_fallback_changes_no_bit(gpu_ctx):
     """The cooperative tail's last resort: an owner whose helpers do not answer in time closes its batch, evaluates all
     of it itself and never publishes again.  With the bound cut to 1 microsecond (RIMPHONY_OWNER_WAIT_US) nearly every
     published batch takes that path, helpers still write late results into abandoned slots -- and the table is the
-    same, bit for bit and status for status, as the normal run's (run in a child process: the variable is read when
+    same, bit for bit, status for status and work counter for work counter, as the normal run's (run in a child process: the variable is read when
     a context is created, and the child's context runs in shared mode next to this one unless it comes first)."""
     code = r'''
 import sys, os
@@ -291,8 +291,8 @@ import numpy as np
 from rimphony_amd import api, workload
 ctx = api.Context(0)
 kind, mask, s, th, params = workload.make_batch("cfg2_powerlaw_8", 192, start=1000000)
-out, st = ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True)
-np.save(sys.argv[1], out); np.save(sys.argv[2], st)
+out, st, work = ctx.compute_batch(kind, s, th, params, 0xFF, want_status=True, want_work=True)
+np.save(sys.argv[1], out); np.save(sys.argv[2], st); np.save(sys.argv[3], work)
 print("shared" if ctx.shared_mode() else "exclusive")
 ''' % ROOT
     import tempfile
@@ -301,10 +301,14 @@ print("shared" if ctx.shared_mode() else "exclusive")
             res = {}
             for name, env_extra in (("normal", {}), ("impatient", {"RIMPHONY_OWNER_WAIT_US": "1"})):
                 env = dict(os.environ, **env_extra)
-                o, s_ = os.path.join(d, name + "_o.npy"), os.path.join(d, name + "_s.npy")
-                r = subprocess.run([sys.executable, "-c", code, o, s_], capture_output=True, text=True, env=env, timeout=600)
+                o, s_, w_ = (os.path.join(d, name + x) for x in ("_o.npy", "_s.npy", "_w.npy"))
+                r = subprocess.run([sys.executable, "-c", code, o, s_, w_], capture_output=True, text=True, env=env,
+                                   timeout=600)
                 assert r.returncode == 0, r.stderr[-2000:]
                 assert "exclusive" in r.stdout
-                res[name] = (np.load(o), np.load(s_))
+                res[name] = (np.load(o), np.load(s_), np.load(w_))
             assert same_bits(res["normal"][0], res["impatient"][0]).all()
             assert (res["normal"][1] == res["impatient"][1]).all()
+            # work counters count what went into the stored value: an abandoned batch that is evaluated again by its
+            # owner is booked once (the owner books a request when it reads the result)
+            assert (res["normal"][2] == res["impatient"][2]).all()
