@@ -6,12 +6,21 @@
 #include "heyvaerts_group.h"
 #include "coop_common.h"
 
-// waves per SIMD the register allocator must leave room for (4 x 16 waves per CU: 10 KB of LDS each)
+// waves per SIMD the register allocator must leave room for.  Symphony groups: 5 (96 VGPRs, 20 waves x 7.6 KB of LDS per
+// CU).  Measured on one MI355X, 32768 six-coefficient power-law rows, after the uniform hints of wave_qag_group:
+// 3 -> 1416 ms, 4 -> 1226 ms, 5 -> 1156 ms (thermal, both pitchy tables and the j_I/alpha_I pair: 5 is 4-5 % faster
+// than 4 as well); 6 does not fit the LDS without shortening the lists (tried with 16 entries: 2.8 x slower).
+// Before the hints 4 was the fastest (5: +6 %).
 #ifndef RIM_GROUP_WAVES
-#define RIM_GROUP_WAVES 4
+#define RIM_GROUP_WAVES 5
 #endif
 #ifndef RIM_HEY_GROUP_WAVES
 #define RIM_HEY_GROUP_WAVES 4
+#endif
+// idle waves that stay per wave that still owns a task at the end of a launch (the surplus leaves: more helpers than a
+// round has entries only add polling traffic)
+#ifndef RIM_GROUP_HELPERS_PER_OWNER
+#define RIM_GROUP_HELPERS_PER_OWNER 64u
 #endif
 // entries of one published round: up to 62 lanes x RIM_GROUP classes
 #define RIM_GROUP_ENTRIES 248

@@ -146,6 +146,9 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
     __syncthreads();
 #endif
     RIM_PROF_T(t_kernel);
+#if defined(RIM_PROF) && !defined(RIM_PROF_COUNTS) && !defined(RIM_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long t_helper = 0;
+#endif
 
     GroupSlot *const my = ga.gboard + blockIdx.x;
     unsigned *const flag_exhausted = a.board_flags + BOARD_FLAG_EXHAUSTED;
@@ -193,6 +196,13 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 const unsigned long long t = wave_next_task(queue, lane);
                 if (t >= ntasks) {
                     helper = true;
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when did the queue run dry, when did the launch end)
+                    if (lane == 0) atomicCAS(a.queue + 12, 0ull, wall_clock64());
+#endif
+                    RIM_PROF_ADD(27, t_kernel);         // owner phase of this wave
+#if defined(RIM_PROF) && !defined(RIM_PROF_COUNTS) && !defined(RIM_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+                    t_helper = __builtin_readcyclecounter();
+#endif
                     if (lane == 0) {
                         __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 if ((n_polls & 15u) == 0) {
                     actw = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // more idle waves than the remaining owners can feed only add polling traffic: the surplus leaves
-                    const unsigned keep = actw * 64u + 32u;
+                    const unsigned keep = actw * RIM_GROUP_HELPERS_PER_OWNER + 32u;
                     if (counted_idle && actw != 0 &&
                         __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > keep) {
                         const unsigned before = __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
             RIM_PROF_T(t_req);
             P::eval(cx, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
             RIM_PROF_ADD(9, t_req);
+            if (helper) RIM_PROF_ADD(28, t_req);        // ... of them, for other waves' tasks
             if (shared) {
                 // hand the members' values, status bits and sample counts back through the board
                 if (lane == 0) {
@@ -569,6 +580,12 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
     }
 
     RIM_PROF_ADD(0, t_kernel);
+#if defined(RIM_TAIL_DIAG)
+    if (g.lane == 0) atomicMax(a.queue + 13, wall_clock64());
+#endif
+#if defined(RIM_PROF) && !defined(RIM_PROF_COUNTS) && !defined(RIM_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+    if (t_helper) RIM_PROF_ADD(29, t_helper);           // helper phase of this wave (helping + polling)
+#endif
     __syncthreads();
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
     if (ga.prof && threadIdx.x < 32) ga.prof[(size_t) blockIdx.x * 32 + threadIdx.x] += rim_prof_lds[threadIdx.x];

@@ -264,6 +264,9 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (t >= ntasks) {
                     helper = true;
                     if (lane == 0) {
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when did the queue run dry, when did the launch end)
+                        atomicCAS(a.queue + (P::QUEUE ? 10 : 12), 0ull, wall_clock64());
+#endif
                         __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (a.board) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -580,6 +583,9 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     }
 
     RIM_PROF_ADD(0, t_kernel);
+#if defined(RIM_TAIL_DIAG)
+    if (g.lane == 0) atomicMax(a.queue + (P::QUEUE ? 11 : 13), wall_clock64());
+#endif
     __syncthreads();
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
     if (threadIdx.x < 32) g_rim_prof[(size_t) blockIdx.x * 32 + threadIdx.x] += rim_prof_lds[threadIdx.x];

@@ -40,7 +40,10 @@ names = {0: "kernel (wave lifetime)",
          22: "  booking from the stash",
          23: "  next integral / first-rule decisions",
          26: "consume (sym_consume of the members that posted)",
-         10: "empty region (timer cost, once per sample pass)"}
+         10: "empty region (timer cost, once per sample pass)",
+         27: "owner phase (until the queue is empty and the own task done)",
+         29: "helper phase (until the wave leaves)",
+         28: "  entries evaluated for other waves"}
 passes = max(w["passes"], 1)
 print("%s mask %#x rows %d: kernel ms %.1f  samples %d passes %d" % (cfg, mask, n, ctx.last_symphony_ms(), w["samples"], w["passes"]))
 for k, nm in names.items():

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""When does the task queue of a launch run dry, and how long does the launch go on after that?  (-DRIM_TAIL_DIAG build:
+tools/build_variant.sh rimphony_amd/librimphony_tail.so -DRIM_TAIL_DIAG; the kernels stamp the 100 MHz wall clock at the
+first empty fetch from the queue and at every wave's exit.)
+usage: RIMPHONY_HIP_LIB=rimphony_amd/librimphony_tail.so python tools/tail_times.py [config] [rows] [start]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rimphony_amd import api, workload
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2_powerlaw_8"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
+start = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
+ctx = api.Context(0)
+dev = torch.device("cuda", 0)
+kind, _, s, th, params = workload.make_batch(cfg, n, start=start)
+d = [torch.from_numpy(x).to(dev) for x in [s, th] + params]
+ctx.compute_batch_device(kind, d[0][:256], d[1][:256], [p[:256] for p in d[2:]], 0xFF)
+for rep in range(2):
+    ctx.compute_batch_device(kind, d[0], d[1], d[2:], 0xFF)
+    torch.cuda.synchronize()
+    c = ctx.debug_counters()
+    t = ctx.last_tail()
+    for name, w0, ms in (("symphony groups", 12, ctx.last_symphony_ms()), ("faraday", 10, ctx.last_faraday_ms())):
+        dry, end = c[w0], c[w0 + 1]
+        print("%s rows %d  %-16s kernel %.1f ms: the launch goes on for %.1f ms after the queue ran dry (%.1f %% of the kernel)"
+              % (cfg, n, name, ms, (end - dry) / 1e5, 100. * ((end - dry) / 1e5) / max(ms, 1e-9)))
+    print("   heaviest chains:", {k: v for k, v in t.items() if "heaviest" in k})
