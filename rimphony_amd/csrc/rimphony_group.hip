@@ -253,7 +253,11 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                     const double val = P::result(cx, sl, T, st);
                     if (lane == 0) {
                         a.out[own_i * 8 + sl] = val;
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: the member's number of batches in the upper half of the status word)
+                        if (a.status) a.status[own_i * 8 + sl] = st | ((P::batches(T) < 0x7fff ? P::batches(T) : 0x7fff) << 16);
+#else
                         if (a.status) a.status[own_i * 8 + sl] = st;
+#endif
                         // the heaviest member of the launch: its sequential chain of batches bounds the launch's tail
                         atomicMax(a.queue + P::TAIL_WORD, ((unsigned long long) P::batches(T) << 24) | ((unsigned long long) own_i & 0xffffffull));
                     }

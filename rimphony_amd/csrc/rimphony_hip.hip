@@ -315,7 +315,11 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     if (lane == 0) atomicMax(a.queue + (P::QUEUE ? 15 : 14), ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: the task's number of batches in the upper half of the status word)
+                        if (a.status) a.status[own_i * 8 + own_slot] = st | ((T.batches < 0x7fff ? T.batches : 0x7fff) << 16);
+#else
                         if (a.status) a.status[own_i * 8 + own_slot] = st;
+#endif
                         if (s_qpark.hb) hb_store(s_qpark.hb + 10, 1ull);
                     }
                 } else {

@@ -16,6 +16,15 @@ dev = torch.device("cuda", 0)
 kind, _, s, th, params = workload.make_batch(cfg, n, start=start)
 d = [torch.from_numpy(x).to(dev) for x in [s, th] + params]
 ctx.compute_batch_device(kind, d[0][:256], d[1][:256], [p[:256] for p in d[2:]], 0xFF)
+out, st = ctx.compute_batch_device(kind, d[0], d[1], d[2:], 0xFF, want_status=True)
+b = (st.cpu().numpy().astype("int64") >> 16) & 0x7fff
+import numpy as np
+for name, cols in (("symphony coefficient", slice(0, 6)), ("faraday coefficient", slice(6, 8))):
+    x = b[:, cols].ravel()
+    print("%s rows %d  batches per %s: median %d  p90 %d  p99 %d  p99.9 %d  max %d;  share of all batches in tasks of >= 64 / 128 / 256 / 512 batches: %.3f %.3f %.3f %.3f;  tasks >= 64 / 128 / 256: %d %d %d"
+          % (cfg, n, name, np.median(x), np.percentile(x, 90), np.percentile(x, 99), np.percentile(x, 99.9), x.max(),
+             x[x >= 64].sum() / x.sum(), x[x >= 128].sum() / x.sum(), x[x >= 256].sum() / x.sum(), x[x >= 512].sum() / x.sum(),
+             (x >= 64).sum(), (x >= 128).sum(), (x >= 256).sum()))
 for rep in range(2):
     ctx.compute_batch_device(kind, d[0], d[1], d[2:], 0xFF)
     torch.cuda.synchronize()
