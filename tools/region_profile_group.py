@@ -44,7 +44,9 @@ names = {0: "kernel (wave lifetime)",
          27: "owner phase (until the queue is empty and the own task done)",
          29: "helper phase (until the wave leaves)",
          28: "  entries evaluated for other waves"}
-passes = max(w["passes"], 1)
-print("%s mask %#x rows %d: kernel ms %.1f  samples %d passes %d" % (cfg, mask, n, ctx.last_symphony_ms(), w["samples"], w["passes"]))
+far = not (mask & 0x3F)            # the Faraday pair in lock-step (RIMPHONY_FARADAY_GROUP=1, mask 0xC0)
+np_, ns_ = (w["faraday_passes"], w["faraday_samples"]) if far else (w["passes"], w["samples"])
+passes = max(np_, 1)
+print("%s mask %#x rows %d: kernel ms %.1f  samples %d passes %d" % (cfg, mask, n, ctx.last_faraday_ms() if far else ctx.last_symphony_ms(), ns_, np_))
 for k, nm in names.items():
     print("%-62s %6.2f %%   %8.1f cycles/pass" % (nm, 100. * c[k] / c[0], c[k] / passes))
