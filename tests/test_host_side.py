@@ -334,3 +334,34 @@ def test_api_refuses_bad_device_inputs():
         ctx.compute_batch_device(0, good, good, [good] * 4)              # host tensors
     with pytest.raises(TypeError):
         ctx.compute_batch_device(0, np.zeros(4), good, [good] * 4)       # not a tensor
+
+
+def test_group_kernel_resources_leave_room_for_its_grid(tmp_path):
+    """The persistent grid of the group kernel is sized for RIM_GROUP_WAVES waves per SIMD (group_launch.h), every one of
+    which must be RESIDENT (a wave that is not is waited for by the cooperative tail up to its 2 s bound: measured as a
+    2 x slower launch on a diagnostic build whose LDS went one allocation granule over).  The compiler's own resource report
+    of the Symphony group kernels must therefore say: that occupancy, and an LDS block that fits 4 x that many times into a
+    CU's 160 KB with one 512-byte granule to spare."""
+    hipcc = _build.find_hipcc()
+    if hipcc is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "rimphony_amd", "csrc", "rimphony_group.hip")
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    r = subprocess.run([hipcc] + flags + ["--cuda-device-only", "-c", src, "-o", str(tmp_path / "g.o"),
+                                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(os.path.join(ROOT, "rimphony_amd", "csrc", "group_launch.h")).read()
+    waves = int(re.search(r"#define RIM_GROUP_WAVES (\d+)", text).group(1))
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "SymGroupProblem" not in name:
+            continue
+        seen += 1
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1))
+        assert occ >= waves, (name, occ)
+        granules = (lds + 511) // 512 * 512
+        assert 4 * waves * granules <= 160 * 1024 - 512, (name, lds)
+    assert seen == 4
