@@ -159,6 +159,10 @@ int rimo_qag_selftest(int family, double p0, double p1, double a, double b, doub
                       size_t limit, double *result, double *abserr, size_t *size_out);
 
 const char *rimo_build_flavour(void);
+/* Investigation knob (tools/faraday_tail_attribution.py only): in the attribution build (liboracle_attr.so, `make attr`)
+ * bit k set = reformulation k of rimo_math.h's RIMO_ATTR_* list evaluated in its LITERAL form; 0 = the deterministic
+ * flavour, RIMO_ATTR_ALL = the literal flavour.  Process-global; a no-op in every other build. */
+void rimo_set_attr_mask(unsigned mask);
 
 /* Investigation knobs (tools/ only; every test and the bench run with the defaults = the reference's values):
  * tolerances and truncation parameters of symphony.rs / heyvaerts.rs that the reference hard-codes, and this

@@ -93,18 +93,19 @@ static double meissel_first(const double n, const double x)
     const double z = x / n;
     const double eps = (n - x) / n;
     const double ninv = 1. / n;
-#ifdef RIMO_LIBM
-    const double Z = m_sqrt(eps * (1 + z));
-    const double U = 1. / (n * Z * Z * Z);
-    /* Gamma(n+1) replaced by (n+1) Gamma(n), as in the reference */
-    const double factor = 1. / ((n + 1.) * m_sqrt(Z));
-#else
-    /* the deterministic flavour takes the three roots from one inverse fourth root, as the kernels do (detmath.h) */
-    double Z, inv_z3, inv_sqrt_z;
-    rim_meissel_roots(eps * (1 + z), &Z, &inv_z3, &inv_sqrt_z);
-    const double U = ninv * inv_z3;
-    const double factor = (1. / (n + 1.)) * inv_sqrt_z;
-#endif
+    double Z, U, factor;
+    if (RIMO_LIT(RIMO_ATTR_BESSEL)) {
+        Z = m_sqrt(eps * (1 + z));
+        U = 1. / (n * Z * Z * Z);
+        /* Gamma(n+1) replaced by (n+1) Gamma(n), as in the reference */
+        factor = 1. / ((n + 1.) * m_sqrt(Z));
+    } else {
+        /* the deterministic flavour takes the three roots from one inverse fourth root, as the kernels do (detmath.h) */
+        double inv_z3, inv_sqrt_z;
+        rim_meissel_roots(eps * (1 + z), &Z, &inv_z3, &inv_sqrt_z);
+        U = ninv * inv_z3;
+        factor = (1. / (n + 1.)) * inv_sqrt_z;
+    }
     const double t1 = z * z;
     const double t2 = ninv * ninv;
 

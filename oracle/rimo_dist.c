@@ -105,23 +105,19 @@ int rimo_dist_init(rimo_dist *d, int kind, const double *params)
  * pitchy_kappa.rs:66-70 write powf(..) * exp(..)).  The literal flavour multiplies the two library values; the
  * deterministic flavour -- the one the kernels are compared with bit for bit -- evaluates one exponential of the
  * double-double sum (rim_powexp_normal, detmath.h), as the kernels do. */
-#ifdef RIMO_LIBM
-#define POWEXP(x, y, e) (pow(x, y) * exp(e))
-#else
-#define POWEXP(x, y, e) rim_powexp_normal(x, y, e)
-#endif
+#define POWEXP(x, y, e) (RIMO_LIT(RIMO_ATTR_POWEXP) ? m_pow(x, y) * m_exp(e) : rim_powexp_normal(x, y, e))
 
 /* (1 + (gamma - 1) / (kappa width))^-(kappa + 1) exp(-gamma / gamma_cutoff) */
 static double kappa_gamma_term(const rimo_dist *d, double gamma)
 {
     const double base = 1. + (gamma - 1.) * d->inv_kappa_width;
     const double y = -(d->par[0] + 1.), e = -gamma * d->inv_gamma_cutoff;
-#ifndef RIMO_LIBM
-    /* the kernels' domain test for the restricted function (dev_symphony.h dist_prepare) */
-    const double kw = d->par[0] * d->par[1];
-    if (rim_isfinite(d->par[0]) && kw > 1e-100 && kw < 1e100)
-        return rim_powexp_normal(base, y, e);
-#endif
+    if (!RIMO_LIT(RIMO_ATTR_POWEXP)) {
+        /* the kernels' domain test for the restricted function (dev_symphony.h dist_prepare) */
+        const double kw = d->par[0] * d->par[1];
+        if (rim_isfinite(d->par[0]) && kw > 1e-100 && kw < 1e100)
+            return rim_powexp_normal(base, y, e);
+    }
     return m_pow(base, y) * m_exp(e);
 }
 
@@ -133,11 +129,9 @@ double rimo_calc_f(const rimo_dist *d, double gamma, double cos_xi)
         if (gamma < d->par[1] || gamma > d->par[2])
             return 0.;
         const double beta = m_sqrt(1. - 1. / (gamma * gamma));
-#ifdef RIMO_LIBM
-        return d->norm * m_pow(gamma, -p) * m_exp(-gamma * d->inv_gamma_cutoff) / (gamma * gamma * beta);
-#else
+        if (RIMO_LIT(RIMO_ATTR_POWEXP))
+            return d->norm * m_pow(gamma, -p) * m_exp(-gamma * d->inv_gamma_cutoff) / (gamma * gamma * beta);
         return d->norm * POWEXP(gamma, -p, -gamma * d->inv_gamma_cutoff) / (gamma * gamma * beta);
-#endif
     }
     case RIMO_THERMAL_JUETTNER:
         return d->norm * m_exp(d->neg_inverse_t * gamma);
@@ -169,14 +163,13 @@ void rimo_calc_f_derivatives(const rimo_dist *d, double gamma, double cos_xi, do
         if (gamma < d->par[1] || gamma > d->par[2]) { *dfdg = 0.; *dfdcx = 0.; return; }
         const double p_plus_1 = d->par[0] + 1.;
         const double g2_minus_1 = gamma * gamma - 1.;
-#ifdef RIMO_LIBM
-        *dfdg = -d->norm * m_pow(gamma, -p_plus_1) / m_sqrt(g2_minus_1) *
-            m_exp(-gamma * d->inv_gamma_cutoff) *
-            (p_plus_1 / gamma + gamma / g2_minus_1 + d->inv_gamma_cutoff);
-#else
-        *dfdg = -d->norm * POWEXP(gamma, -p_plus_1, -gamma * d->inv_gamma_cutoff) / m_sqrt(g2_minus_1) *
-            (p_plus_1 / gamma + gamma / g2_minus_1 + d->inv_gamma_cutoff);
-#endif
+        if (RIMO_LIT(RIMO_ATTR_POWEXP))
+            *dfdg = -d->norm * m_pow(gamma, -p_plus_1) / m_sqrt(g2_minus_1) *
+                m_exp(-gamma * d->inv_gamma_cutoff) *
+                (p_plus_1 / gamma + gamma / g2_minus_1 + d->inv_gamma_cutoff);
+        else
+            *dfdg = -d->norm * POWEXP(gamma, -p_plus_1, -gamma * d->inv_gamma_cutoff) / m_sqrt(g2_minus_1) *
+                (p_plus_1 / gamma + gamma / g2_minus_1 + d->inv_gamma_cutoff);
         *dfdcx = 0.;
         return;
     }

@@ -54,11 +54,9 @@ double rimo_gamma_real(double z)
     double prod = 1., w = z;
     int guard = 0;
     while (w < 16. && guard < 64) { prod = prod * w; w = w + 1.; guard++; }
-#ifdef RIMO_LIBM
-    return exp(lgamma(w)) / prod;
-#else
+    if (RIMO_LIT(RIMO_ATTR_ELEM))
+        return exp(lgamma(w)) / prod;
     return rim_exp(rim_lgamma_stirling(w)) / prod;
-#endif
 }
 
 /* work counters of the calling thread's Heyvaerts evaluation (null outside one) */
@@ -78,7 +76,6 @@ static double ascending_series(double nu, double q, double sign)
     return sum;
 }
 
-#ifndef RIMO_LIBM
 /* the same series for the four fixed orders of the quasi-resonant elements as the kernels sum it (dev_heyvaerts.h
  * ascending_series_tab): each term the previous one times q times the rounded reciprocal of k (k + nu), two terms
  * per convergence test */
@@ -97,37 +94,41 @@ static double ascending_series_pairs(double nu, double q)
     if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) (k <= 500 ? k + 1 : 500); t_ctr->hey_series_calls += 1; }
     return sum;
 }
-#endif
 
 double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x > 0 */
 {
     const double h = 0.5 * x;
-#ifndef RIMO_LIBM
     /* the four orders of the quasi-resonant elements: the deterministic flavour takes (x/2)^nu from one cube root and
-     * 1 / Gamma(1 + nu) as a constant, as the kernels do (rim_third_powers, detmath.h) */
+     * 1 / Gamma(1 + nu) as a constant, and sums the series two terms per test with tabulated reciprocals, as the kernels
+     * do (rim_third_powers, detmath.h; dev_heyvaerts.h ascending_series_tab); the two are separate switches of the
+     * attribution build */
     static const double ORD[4] = { 2. / 3., -2. / 3., 1. / 3., -1. / 3. };
     static const double RGAM[4] = { RIM_RGAMMA_5_3, RIM_RGAMMA_1_3, RIM_RGAMMA_4_3, RIM_RGAMMA_2_3 };
     for (int j = 0; j < 4; j++)
         if (nu == ORD[j]) {
-            double pref[4];
-            rim_third_powers(h, pref);
-            return (pref[j] * RGAM[j]) * ascending_series_pairs(nu, h * h);
+            double prefactor;
+            if (RIMO_LIT(RIMO_ATTR_THIRD)) {
+                prefactor = m_pow(h, nu) / rimo_gamma_real(nu + 1.);
+            } else {
+                double pref[4];
+                rim_third_powers(h, pref);
+                prefactor = pref[j] * RGAM[j];
+            }
+            return prefactor * (RIMO_LIT(RIMO_ATTR_SERIES) ? ascending_series(nu, h * h, 1.) : ascending_series_pairs(nu, h * h));
         }
-#endif
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, 1.);
 }
 
 double rimo_bessel_jnu(double nu, double x)  /* J_nu(x), x > 0, small x */
 {
     const double h = 0.5 * x;
-#ifndef RIMO_LIBM
-    /* the deterministic flavour multiplies by 1 / Gamma from the short-range series where it applies, as the kernels do */
-    const double z = nu + 1.;
-    const double rg = RIM_RGAMMA_NEAR(z) ? rim_rgamma_near(z) : 1. / rimo_gamma_real(z);
-    return m_pow(h, nu) * rg * ascending_series(nu, h * h, -1.);
-#else
+    if (!RIMO_LIT(RIMO_ATTR_RGAMMA)) {
+        /* the deterministic flavour multiplies by 1 / Gamma from the short-range series where it applies, as the kernels do */
+        const double z = nu + 1.;
+        const double rg = RIM_RGAMMA_NEAR(z) ? rim_rgamma_near(z) : 1. / rimo_gamma_real(z);
+        return m_pow(h, nu) * rg * ascending_series(nu, h * h, -1.);
+    }
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, -1.);
-#endif
 }
 
 double rimo_bessel_ynu(double nu, double x)  /* Y_nu(x) by reflection */
@@ -315,13 +316,9 @@ static double nr_inner_cb(double sigma, void *ctx)
     hey_state *st = (hey_state *) ctx;
     fill_coord_vars(st, sigma, st->fixed);
     if (st->c) { st->c->integrand_evals++; st->c->hey_nr_samples++; }
-#ifdef RIMO_LIBM
-    (void) h_nr_element_det; (void) f_nr_element_det;
-    return st->stokes == RIMO_STOKES_Q ? h_nr_element(st) : f_nr_element(st);
-#else
-    (void) h_nr_element; (void) f_nr_element;
+    if (RIMO_LIT(RIMO_ATTR_NR))
+        return st->stokes == RIMO_STOKES_Q ? h_nr_element(st) : f_nr_element(st);
     return st->stokes == RIMO_STOKES_Q ? h_nr_element_det(st) : f_nr_element_det(st);
-#endif
 }
 
 static double qr_inner_cb(double pomega, void *ctx)

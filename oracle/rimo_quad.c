@@ -25,7 +25,7 @@ static double rescale_error(double err, const double result_abs, const double re
 {
     err = m_fabs(err);
     if (result_asc != 0 && err != 0) {
-        double scale = m_pow15(200 * err / result_asc);
+        double scale = m_pow15_rescale(200 * err / result_asc);
         if (scale < 1)
             err = result_asc * scale;
         else
@@ -39,7 +39,7 @@ static double rescale_error(double err, const double result_abs, const double re
     return err;
 }
 
-#if !defined(RIMO_LIBM) && !defined(RIMO_GK_PER_NODE)
+#if !defined(RIMO_GK_PER_NODE)
 /* The deterministic flavour forms QUADPACK's own terms -- w (f1 + f2) per symmetric pair of nodes, the centre alone --
  * and adds the 16 terms in the order of the wavefront kernel: pair k of the rule (abscissa xgk[k], k = 0..14; slot 15
  * is the centre) sits on lanes 2k and 2k + 1 of a half-wave, the first butterfly step (xor 1) is the pair sum
@@ -69,9 +69,12 @@ void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
         fv[j] = f(center + half_length * GK_X[j], ctx);
     fv[31] = 0.0;
 
-#ifdef RIMO_LIBM
+#if defined(RIMO_GK_PER_NODE)
+    if (0) {
+#else
     /* QUADPACK order: centre, 7 Gauss pairs, 8 Kronrod-only pairs (xgk[k] = -GK_X[k]) */
-    {
+    if (RIMO_LIT(RIMO_ATTR_GKSEQ)) {
+#endif
         const double f_center = fv[15];
         result_gauss = f_center * GK_WG[15];
         result_kronrod = f_center * GK_WK[15];
@@ -106,8 +109,8 @@ void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
             result_asc += GK_WK[jtwm1] * (m_fabs(fv[jtwm1] - mean) + m_fabs(fv[30 - jtwm1] - mean));
         }
     }
-#elif defined(RIMO_GK_PER_NODE)
-    {
+#if defined(RIMO_GK_PER_NODE)
+    else {
         /* The deterministic flavour as it was until round 2 (tools/nan_rootcause.py only): one product w f per NODE,
          * 32 terms in the butterfly order.  With subnormal samples every product rounds to whole quanta of 2^-1074, so
          * the products of small samples vanish where qk.c's pair terms w (f1 + f2) survive: the cause of the one-sided
@@ -125,7 +128,7 @@ void rimo_qk31(rimo_fn f, void *ctx, double a, double b,
         TREE32(t); result_asc = t[0];
     }
 #else
-    {
+    else {
         /* slot k < 15: the pair (node k, node 30 - k) of the ascending table, weight GK_WK[k] = GK_WK[30 - k]; slot 15: centre */
         double t[16];
         for (int k = 0; k < 15; k++) t[k] = GK_WK[k] * (fv[k] + fv[30 - k]);
@@ -506,6 +509,13 @@ double rimo_hyperg_2F1_at_1(double a, double b, double c)
     return m_exp(lc + lcab - lca - lcb);
 }
 
+#ifdef RIMO_ATTR
+unsigned rimo_attr_mask = 0;
+void rimo_set_attr_mask(unsigned mask) { rimo_attr_mask = mask; }
+#else
+void rimo_set_attr_mask(unsigned mask) { (void) mask; }
+#endif
+
 const char *rimo_build_flavour(void)
 {
 #if defined(RIMO_LIBM) && defined(RIMO_GK_REVERSED)
@@ -514,6 +524,8 @@ const char *rimo_build_flavour(void)
     return "libm+gsl-order+contracted";
 #elif defined(RIMO_LIBM)
     return "libm+gsl-order";
+#elif defined(RIMO_ATTR)
+    return "attribution build (detmath+tree-order with run-time literal switches)";
 #elif defined(RIMO_GK_PER_NODE)
     return "detmath+tree-order, per-node products (round 2)";
 #else

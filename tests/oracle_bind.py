@@ -29,7 +29,8 @@ _cache = {}
 
 
 def load(flavour="det"):
-    name = "liboracle.so" if flavour == "det" else "liboracle_libm.so"
+    # "det" / "libm": the two flavours `make all` builds; any other name is liboracle_<name>.so (`make controls`, `make attr`)
+    name = {"det": "liboracle.so", "libm": "liboracle_libm.so"}.get(flavour, "liboracle_%s.so" % flavour)
     if name in _cache:
         return _cache[name]
     path = os.path.join(ROOT, "oracle", name)

@@ -19,11 +19,14 @@ import re
 for d in dirs:
     log = os.path.join(os.path.dirname(d.rstrip("/")), "log1.txt")
     if os.path.exists(log):
-        m = re.search(r"^kernel ms ([0-9.]+) samples (\d+) passes (\d+) inner_qags (\d+)", open(log).read(), re.M)
-        if m:
-            for r in res:
-                if "Heyvaerts" not in r["kernel"]:
-                    r["work"] = {"kernel_ms_under_pmc": float(m.group(1)), "samples": int(m.group(2)), "passes": int(m.group(3)), "inner_qags": int(m.group(4))}
+        text = open(log).read()
+        for pat, faraday in ((r"^kernel ms ([0-9.]+) samples (\d+) passes (\d+) inner_qags (\d+)", False),
+                             (r"^faraday kernel ms ([0-9.]+) samples (\d+) passes (\d+) inner_qags (\d+)", True)):
+            m = re.search(pat, text, re.M)
+            if m:
+                for r in res:
+                    if ("Heyvaerts" in r["kernel"] or "HeyGroup" in r["kernel"]) == faraday:
+                        r["work"] = {"kernel_ms_under_pmc": float(m.group(1)), "samples": int(m.group(2)), "passes": int(m.group(3)), "inner_qags": int(m.group(4))}
         break
 # the build the counters were taken on: bench.py only quotes them for that build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
