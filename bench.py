@@ -14,11 +14,14 @@ Side objects of the JSON line:
                     lock-step): algorithmic flops = device-counted integrand samples (the REFERENCE's count: every
                     coefficient's own samples, whether or not the kernel shared their evaluation) x the hand-counted flops
                     per sample, over the kernel's HIP-event time, against the fp64 vector peak; `traffic` = HBM bytes per
-                    launch from the committed PMC profile of THIS build (profiles/r3_pmc_*.json carries the sample count of
-                    the profiled launch and the source id of the build; a stale profile is refused, traffic = null)
+                    launch from the committed PMC profile of THIS build (profiles/r4_pmc_*.json carries the sample count of
+                    the profiled launch and the source id of the build; a stale profile is refused, traffic = null);
+                    `executed` = the fp64 work the vector unit really did (PMC instruction counts per pass x this run's
+                    passes): the hardware-utilisation figure, below `achieved` where samples are shared
   roofline_faraday  the same for coop_kernel<HeyvaertsProblem<0>> (rho_Q, rho_V)
   two_coeff         BASELINE configs[1] (power law, j_I + alpha_I only), with its own roofline
   thermal_eight     configs[2]'s table (thermal Juettner, eight coefficients)
+  pitchypl_eight, pitchykappa_eight   configs[3] / configs[4]'s tables (the anisotropic distributions), with both rooflines
   corner / gmin1    SURVEY 8d's two separately-reported variants: theta < 0.05, and gamma_min = 1 as in the golden file
   parity            HIP output against the committed vectors of the oracle's LITERAL flavour (tests/golden/literal_*.npz:
                     glibc libm, unfused, GSL summation order) -- the stand-in for BASELINE's "max rel-err vs Rust/GSL ref"
@@ -39,10 +42,19 @@ sys.path.insert(0, ROOT)
 # DESIGN.md "Algorithmic work per unit": fp64 flops per integrand sample (FMA = 2; add, mul, div, sqrt = 1; elementary
 # functions expanded), counted from the source and weighted with the measured branch mix of each table.  These are
 # MODELS of the algorithmic work, not counter readings; the executed instruction mix is in profiles/r3_pmc_*.json.
-SYMPHONY_FLOPS = {"cfg2_powerlaw_jI_aI": 720.0, "cfg2_powerlaw_8": 720.0, "cfg3_thermal_8": 600.0}
-FARADAY_FLOPS = {"cfg2_powerlaw_8": 498.0, "cfg3_thermal_8": 617.0}      # profiles/r2_faraday_flop_model.txt
+# The anisotropic tables: the power-law sample (720) plus the pitch-angle factor sin^k xi -- one sqrt, one pow (90) and
+# three products, + d f / d cos xi on the absorption side (pitchy_pl.rs:32-64) = 816; pitchy kappa: the thermal sample
+# (600) with exp (34 + 8) replaced by the kappa power and the cutoff exponential (pow 90 + exp 34 + 4), the same
+# pitch-angle factor (94) and the derivative's quotient (8) (pitchy_kappa.rs:38-62) = 788.
+SYMPHONY_FLOPS = {"cfg2_powerlaw_jI_aI": 720.0, "cfg2_powerlaw_8": 720.0, "cfg3_thermal_8": 600.0,
+                  "cfg4_pitchypl_8": 816.0, "cfg5_pitchykappa_8": 788.0}
+# tools/faraday_flop_model.py (profiles/r2_faraday_flop_model.txt): hand count of the reference's elements x the
+# oracle-measured branch mix of each table
+FARADAY_FLOPS = {"cfg2_powerlaw_8": 498.0, "cfg3_thermal_8": 617.0, "cfg4_pitchypl_8": 902.0, "cfg5_pitchykappa_8": 1081.0}
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X public spec, 256 CUs x 128 flop/clk x 2.4 GHz
-PMC_PROFILE = "profiles/r3_pmc_group_powerlaw8.json"
+# committed counter profiles of ONE launch of each persistent kernel on the power-law table (tools/pmc_collect.sh):
+# HBM bytes and executed fp64 instructions per sample / per pass, quoted only for the build they were taken on
+PMC_PROFILES = {"group_kernel": "profiles/r4_pmc_group_powerlaw8.json", "Heyvaerts": "profiles/r4_pmc_faraday_powerlaw8.json"}
 TABLE = 1_000_000
 REFERENCE_HINT = ("the reference's only timing statement: benches/powerlaw.rs:6-8, 'about 40 minutes' for 16 single-coefficient "
                   "benchmarks x >= 300 iterations on its author's machine, i.e. about 0.5 s per coefficient on one core")
@@ -127,7 +139,7 @@ def main():
         """`warmup` untimed + `steps` timed steps of `rows` rows per GPU; timed region bracketed by barrier + synchronize on
         both sides, max over ranks.  Returns the whole-job time, per-kernel HIP-event times and device work counters."""
         shards = [stage(config, rows, start0 + (st * rows * world) % wrap) for st in range(warmup + steps)]
-        sym_ms, far_ms, sym_samples, sym_passes, far_samples = [], [], [], [], []
+        sym_ms, far_ms, sym_samples, sym_passes, far_samples, far_passes = [], [], [], [], [], []
 
         def run(i, record):
             kind, mask, d = shards[i]
@@ -146,6 +158,7 @@ def main():
                 sym_samples.append(wk["samples"])
                 sym_passes.append(wk["passes"])
                 far_samples.append(wk["faraday_samples"])
+                far_passes.append(wk["faraday_passes"])
 
         for i in range(warmup):
             run(i, False)
@@ -156,25 +169,30 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         return {"dt": dt, "sym_ms": sym_ms, "far_ms": far_ms, "sym_samples": sym_samples, "sym_passes": sym_passes,
-                "far_samples": far_samples}
+                "far_samples": far_samples, "far_passes": far_passes}
 
-    def pmc_traffic(avg_samples):
-        """HBM bytes of one launch of the dominant kernel: (FETCH_SIZE + WRITE_SIZE, KB) per sample of the committed PMC
-        profile x the samples of this run's launch -- only if the profile was taken on this build."""
-        path = os.path.join(ROOT, PMC_PROFILE)
+    def pmc_record(kernel):
+        """The committed PMC record of `kernel`'s family, or (None, why): only a profile of THIS build is quoted."""
+        fam = next((f for f in PMC_PROFILES if f in kernel), None)
+        if fam is None:
+            return None, "no PMC profile for this kernel"
+        path = os.path.join(ROOT, PMC_PROFILES[fam])
         if not os.path.exists(path):
-            return None, "no PMC profile committed (%s)" % PMC_PROFILE
-        recs = json.load(open(path))
-        rec = next((r for r in recs if "group_kernel" in r["kernel"]), None)
+            return None, "no PMC profile committed (%s)" % PMC_PROFILES[fam]
+        rec = next((r for r in json.load(open(path)) if fam in r["kernel"]), None)
         if rec is None or "work" not in rec or not rec["work"].get("samples"):
             return None, "PMC profile without the launch's sample count"
         if rec.get("source_id") != _build.source_id():
-            return None, "stale: %s was taken on source id %s, this build is %s" % (PMC_PROFILE, rec.get("source_id"), _build.source_id())
-        per_sample = (rec["counters"]["FETCH_SIZE"] + rec["counters"]["WRITE_SIZE"]) * 1024. / rec["work"]["samples"]
-        return round(per_sample * avg_samples), ("PMC FETCH_SIZE + WRITE_SIZE of %s (%d samples in that launch, same source id) "
-                                                 "scaled to the samples of this run's launch" % (PMC_PROFILE, rec["work"]["samples"]))
+            return None, "stale: %s was taken on source id %s, this build is %s" % (PMC_PROFILES[fam], rec.get("source_id"), _build.source_id())
+        rec["path"] = PMC_PROFILES[fam]
+        return rec, None
 
-    def roofline(kernel, flops_per_sample, ms, samples, passes=None, with_traffic=False):
+    def roofline(kernel, flops_per_sample, ms, samples, passes=None, with_traffic=False, kind=0):
+        """`achieved` / `frac`: ALGORITHMIC work (the reference's samples x modelled flops per sample) over the kernel's
+        HIP-event time -- the contract's definition; a kernel that shares samples between coefficients scores above
+        its hardware utilisation here.  `executed`: what the vector unit actually did -- fp64 flop-lanes per executed
+        pass from the committed PMC profile of this build (2 FMA + ADD + MUL + TRANS instructions x 64 lanes,
+        masked-off lanes included) x the passes counted on the device in this run: the utilisation figure."""
         avg_s = float(np.mean(ms)) * 1e-3
         avg_samples = float(np.mean(samples))
         achieved = avg_samples * flops_per_sample / avg_s / 1e12
@@ -182,14 +200,32 @@ def main():
              "frac": round(achieved / FP64_VECTOR_PEAK_TFLOPS, 5), "traffic": None,
              "kernel": kernel, "kernel_ms": round(avg_s * 1e3, 3), "samples_per_launch": avg_samples,
              "flops_per_sample": flops_per_sample,
-             "flops_kind": "modelled: hand-counted algorithmic flops per integrand sample of the reference's algorithm "
-                           "(DESIGN.md section 5) x the reference's sample count, counted on the device in this run"}
+             "flops_kind": "ALGORITHMIC: hand-counted flops per integrand sample of the reference's algorithm "
+                           "(DESIGN.md section 5) x the reference's sample count, counted on the device in this run; "
+                           "not a utilisation figure -- see `executed`"}
         if passes:
             # 62 samples per pass and coefficient in the reference's scheme; the group kernel serves several
             # coefficients with one pass
             r["samples_per_executed_pass"] = round(avg_samples / float(np.mean(passes)), 2)
-        if with_traffic:
-            r["traffic"], r["traffic_kind"] = pmc_traffic(avg_samples)
+        rec, why = pmc_record(kernel)
+        if rec is not None and kind == 0:
+            c = rec["counters"]
+            if with_traffic:
+                per_sample = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024. / rec["work"]["samples"]
+                r["traffic"] = round(per_sample * avg_samples)
+                r["traffic_kind"] = ("PMC FETCH_SIZE + WRITE_SIZE of %s (%d samples in that launch, same source id) scaled to "
+                                     "the samples of this run's launch" % (rec["path"], rec["work"]["samples"]))
+            if passes and rec["work"].get("passes"):
+                lanes = 64. * (2. * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"]
+                               + c["SQ_INSTS_VALU_TRANS_F64"]) / rec["work"]["passes"]
+                ex = lanes * float(np.mean(passes)) / avg_s / 1e12
+                r["executed"] = {"tflops": round(ex, 3), "frac": round(ex / FP64_VECTOR_PEAK_TFLOPS, 5),
+                                 "fp64_flop_lanes_per_pass": round(lanes, 1),
+                                 "valu_per_pass": round(c["SQ_INSTS_VALU"] / rec["work"]["passes"], 1),
+                                 "valu_busy": round(c["SQ_ACTIVE_INST_VALU"] * 4. / 1024. / (c["GRBM_GUI_ACTIVE"] / 8.), 4),
+                                 "basis": "PMC instruction counts per executed pass of %s (same source id) x this run's passes" % rec["path"]}
+        elif with_traffic:
+            r["traffic_kind"] = why
         kms = minmax_over_ranks(avg_s * 1e3)
         if distributed:
             r["kernel_ms_min_max_over_ranks"] = [round(kms[0], 3), round(kms[1], 3)]
@@ -205,10 +241,10 @@ def main():
                "workload": "%s, rows %d.. of the generator" % (cfg, start0)}
         if with_roofline and leg["sym_ms"]:
             obj["roofline_symphony"] = roofline("group_kernel<%d>" % kind, SYMPHONY_FLOPS.get(base, 720.0), leg["sym_ms"],
-                                                leg["sym_samples"], leg["sym_passes"])
+                                                leg["sym_samples"], leg["sym_passes"], kind=kind)
         if with_roofline and leg["far_ms"]:
             obj["roofline_faraday"] = roofline("coop_kernel<HeyvaertsProblem<%d>>" % kind, FARADAY_FLOPS.get(base, 498.0),
-                                               leg["far_ms"], leg["far_samples"])
+                                               leg["far_ms"], leg["far_samples"], leg["far_passes"], kind=kind)
         return obj
 
     # ---------------------------------------------------------------- primary: eight coefficients per point, per the contract
@@ -220,18 +256,22 @@ def main():
     # (every rank takes part: the per-rank kernel-time spread is a collective)
     base_cfg = args.config
     roof = roofline("group_kernel<%d>" % kind, SYMPHONY_FLOPS.get(base_cfg, 720.0), primary["sym_ms"],
-                    primary["sym_samples"], primary["sym_passes"], with_traffic=True) if primary["sym_ms"] else None
+                    primary["sym_samples"], primary["sym_passes"], with_traffic=True, kind=kind) if primary["sym_ms"] else None
     roof_far = roofline("coop_kernel<HeyvaertsProblem<%d>>" % kind, FARADAY_FLOPS.get(base_cfg, 498.0), primary["far_ms"],
-                        primary["far_samples"]) if primary["far_ms"] else None
+                        primary["far_samples"], primary["far_passes"], with_traffic=True, kind=kind) if primary["far_ms"] else None
     tail = ctx.last_tail()
 
 
     # ---------------------------------------------------------------- side legs
-    two = thermal = corner = gmin1 = None
+    two = thermal = corner = gmin1 = pitchypl = pitchykappa = None
     if args.side_rows > 0:
         R = args.side_rows
         two = side_leg("cfg2_powerlaw_jI_aI", min(4 * R, 262144), 2, 0)
         thermal = side_leg("cfg3_thermal_8", R, 2, 0)
+        # configs[3] / configs[4]: the two anisotropic tables -- the crank-out product's actual workload
+        # (examples/crank-out-pitchypl.rs:157-195, crank-out-pitchykappa.rs:184-217); one warm-up + one timed step each
+        pitchypl = side_leg("cfg4_pitchypl_8", R, 1, 0)
+        pitchykappa = side_leg("cfg5_pitchykappa_8", R, 1, 0)
         corner = side_leg("cfg2_powerlaw_8_corner", min(R, 2048), 1, TABLE, with_roofline=False)
         gmin1 = side_leg("cfg2_powerlaw_8_gmin1", min(R, 16384), 1, TABLE, with_roofline=False)
 
@@ -315,7 +355,8 @@ def main():
                                   "faraday_heaviest_row": tail["faraday_heaviest_row"],
                                   "note": "the sequential chain of batches of the heaviest task bounds how early a launch can end"},
             "cpu_baseline": cpu,
-            "two_coeff": two, "thermal_eight": thermal, "corner_theta_lt_0.05": corner, "gamma_min_1": gmin1, "parity": parity,
+            "two_coeff": two, "thermal_eight": thermal, "pitchypl_eight": pitchypl, "pitchykappa_eight": pitchykappa,
+            "corner_theta_lt_0.05": corner, "gamma_min_1": gmin1, "parity": parity,
             "shared_mode": int(ctx.shared_mode()) if hasattr(ctx, "shared_mode") else None,
         }
         print(json.dumps(line))

@@ -48,14 +48,21 @@ static double rust_max(double a, double b) { if (a != a) return b; if (b != b) r
 
 /* ---- special functions --------------------------------------------------- */
 
-/* Gamma(z) for real z (poles give +-inf): shift above 16, Stirling, divide back. */
+/* Gamma(z) for real z.  Deterministic flavour (shared with the kernels' gamma_real, dev_heyvaerts.h): shift above 16,
+ * Stirling, divide back (poles give +-inf).  Literal flavour: the C library's long double Gamma function rounded to
+ * double -- the stand-in for the Gamma function inside special-fun's Bessel routines, whose source is absent; a library
+ * Gamma is good to an ulp or two.  (Until round 3 the literal flavour formed exp(lgamma(w)) / prod, whose relative error
+ * is |lgamma(w)| ulps -- 15 to 27 ulp at the four arguments 1 + nu the quasi-resonant elements need, always with the
+ * same sign; the difference I_(-nu) - I_nu of heyvaerts.rs:337, 365 amplifies that by up to 3e8 at g -> 10, and
+ * tools/faraday_tail_attribution.py showed that this one quantity owned the whole tail of rho_Q / rho_V beyond 1e-6
+ * between the kernels and the literal vectors: profiles/r4_faraday_tail_attribution.txt.) */
 double rimo_gamma_real(double z)
 {
+    if (RIMO_LIT(RIMO_ATTR_ELEM))
+        return (double) tgammal((long double) z);
     double prod = 1., w = z;
     int guard = 0;
     while (w < 16. && guard < 64) { prod = prod * w; w = w + 1.; guard++; }
-    if (RIMO_LIT(RIMO_ATTR_ELEM))
-        return exp(lgamma(w)) / prod;
     return rim_exp(rim_lgamma_stirling(w)) / prod;
 }
 
@@ -77,31 +84,35 @@ static double ascending_series(double nu, double q, double sign)
 }
 
 /* the same series for the four fixed orders of the quasi-resonant elements as the kernels sum it (dev_heyvaerts.h
- * ascending_series_tab): each term the previous one times q times the rounded reciprocal of k (k + nu), two terms
- * per convergence test */
-static double ascending_series_pairs(double nu, double q)
+ * rim_iseries4): Horner's rule on the correctly rounded coefficients 1 / (k! (nu + 1)_k) (iseries_table.h), from a
+ * degree chosen by q alone */
+#include "../rimphony_amd/csrc/iseries_table.h"
+static const double ISERIES[4 * (RIM_ISERIES_NMAX + 1)] = RIM_ISERIES_TABLE;
+static double iseries_horner(int j, double q)
 {
-    double term = 1., sum = 1.;
-    int k;
-    for (k = 1; k <= 500; k += 2) {
-        const double c1 = 1. / (k * (k + nu)), c2 = 1. / ((k + 1) * ((k + 1) + nu));
-        term = term * (q * c1);
-        sum = sum + term;
-        term = term * (q * c2);
-        sum = sum + term;
-        if (m_fabs(term) < 1e-17 * m_fabs(sum)) break;
+    static const double QMIN[6] = { RIM_ISERIES_Q21, RIM_ISERIES_Q18, RIM_ISERIES_Q15, RIM_ISERIES_Q12, RIM_ISERIES_Q9, RIM_ISERIES_Q6 };
+    double s = 0.;
+    int terms = 7;
+    for (int b = 0; b < 6; b++) {          /* blocks of three terms, degree 24 downwards */
+        if (q >= QMIN[b]) {
+            const int k = 24 - 3 * b;
+            s = rim_fma(s, q, ISERIES[4 * k + j]);
+            s = rim_fma(s, q, ISERIES[4 * (k - 1) + j]);
+            s = rim_fma(s, q, ISERIES[4 * (k - 2) + j]);
+            terms += 3;
+        }
     }
-    if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) (k <= 500 ? k + 1 : 500); t_ctr->hey_series_calls += 1; }
-    return sum;
+    for (int k = 6; k >= 0; k--) s = rim_fma(s, q, ISERIES[4 * k + j]);
+    if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) terms; t_ctr->hey_series_calls += 1; }
+    return s;
 }
 
 double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x > 0 */
 {
     const double h = 0.5 * x;
     /* the four orders of the quasi-resonant elements: the deterministic flavour takes (x/2)^nu from one cube root and
-     * 1 / Gamma(1 + nu) as a constant, and sums the series two terms per test with tabulated reciprocals, as the kernels
-     * do (rim_third_powers, detmath.h; dev_heyvaerts.h ascending_series_tab); the two are separate switches of the
-     * attribution build */
+     * 1 / Gamma(1 + nu) as a constant, and sums the series by Horner's rule, as the kernels do (rim_third_powers,
+     * detmath.h; dev_heyvaerts.h rim_iseries4); the two are separate switches of the attribution build */
     static const double ORD[4] = { 2. / 3., -2. / 3., 1. / 3., -1. / 3. };
     static const double RGAM[4] = { RIM_RGAMMA_5_3, RIM_RGAMMA_1_3, RIM_RGAMMA_4_3, RIM_RGAMMA_2_3 };
     for (int j = 0; j < 4; j++)
@@ -114,7 +125,7 @@ double rimo_bessel_i(double nu, double x)   /* receiver.besseli(nu): I_nu(x), x 
                 rim_third_powers(h, pref);
                 prefactor = pref[j] * RGAM[j];
             }
-            return prefactor * (RIMO_LIT(RIMO_ATTR_SERIES) ? ascending_series(nu, h * h, 1.) : ascending_series_pairs(nu, h * h));
+            return prefactor * (RIMO_LIT(RIMO_ATTR_SERIES) ? ascending_series(nu, h * h, 1.) : iseries_horner(j, h * h));
         }
     return m_pow(h, nu) / rimo_gamma_real(nu + 1.) * ascending_series(nu, h * h, 1.);
 }

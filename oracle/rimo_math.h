@@ -17,7 +17,7 @@
 enum {
     RIMO_ATTR_THIRD    = 1 << 0,   /* (x/2)^nu / Gamma(1+nu) of the four fixed-order I_nu: pow + Gamma, not rim_third_powers + constants */
     RIMO_ATTR_RGAMMA   = 1 << 1,   /* 1/Gamma(nu+1) of the J_nu prefactors: a division by Gamma, not rim_rgamma_near */
-    RIMO_ATTR_SERIES   = 1 << 2,   /* fixed-order I_nu series: term-by-term division and test, not pairs with tabulated reciprocals */
+    RIMO_ATTR_SERIES   = 1 << 2,   /* fixed-order I_nu series: the term recurrence with a division and a test per term, not Horner on tabulated coefficients */
     RIMO_ATTR_NR       = 1 << 3,   /* h_nr / f_nr: divisions by powers of sigma^2 - x^2, not products of powers of u */
     RIMO_ATTR_POW15    = 1 << 4,   /* x^1.5, x^2.5, x^(4/3) of the elements and range limits through pow(), not x sqrt(x) / x cbrt(x) */
     RIMO_ATTR_ELEM     = 1 << 5,   /* exp, log, pow, lgamma from glibc, not detmath.h */

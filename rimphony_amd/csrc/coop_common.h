@@ -52,7 +52,6 @@ struct SymArgs {
     double *spill;                  // [gridDim.x][SPILL_DOUBLES_PER_WAVE] wave-private global store overflow
     struct AssistSlot *board;       // [gridDim.x] cooperative-tail board (null: cooperation off)
     unsigned *board_flags;          // [0] task queue exhausted, [1] waves that still own / may fetch a task
-    const double *series_tab;       // Heyvaerts: divisors of the fixed-order Bessel series and their reciprocals
     unsigned long long *heartbeat;  // diagnostics: host-mapped words written by the wave that owns hb_task
     unsigned long long hb_task;
     unsigned long long *work;       // optional [n][8]: integrand samples spent on each coefficient (null: not counted)

@@ -59,60 +59,72 @@ RIM_DEV double ascending_series(double nu, double q, double sign)
     return sum;
 }
 
-// The four fixed orders of the quasi-resonant elements (nu = 2/3, -2/3, 1/3, -1/3) divide every series
-// term by k (k + nu), a number that depends on nothing else: a table of those divisors and of their
-// correctly rounded reciprocals turns each of the ~40 divisions per series into the exact 3-operation
-// form (rim_div_by).  Layout: [4 orders][RIM_SERIES_TERMS + 1][2] doubles = {k (k + nu), 1 / that}.
-#define RIM_SERIES_TERMS 500
-#define RIM_SERIES_ROW (2 * (RIM_SERIES_TERMS + 1))
+// The ascending series of the four modified Bessel functions of a quasi-resonant sample (orders 2/3, -2/3, 1/3, -1/3),
+//   S_j(q) = sum_k a[k][j] q^k,   a[k][j] = 1 / (k! (nu_j + 1)_k),   q = (g/2)^2 < 25   (iseries_table.h, generated),
+// by Horner's rule -- one FMA per term and order, the four orders side by side -- from a degree that depends on q ALONE:
+// degree 6 for every lane, three more terms for the lanes whose q is beyond each threshold (below it the terms left out
+// are under 2^-60 of the sum).  A lane that enters at degree n starts from 0, so its first step leaves a[n][j]: the value
+// is a function of q and of nothing else -- not of the other lanes of the wave, which only decide which blocks are
+// skipped.  The coefficients are wave-uniform constants (scalar loads / the scalar operand of v_fma_f64).  Until round 3
+// the terms were built by the recurrence term *= q / (k (k + nu)), two products and a sum per term plus a convergence test
+// per pair of terms; Horner is 0.5-0.8 ulp rms from the true sum where the recurrence is 1.3-1.9 (tests/test_detmath.py).
+#include "iseries_table.h"
+#if defined(__HIP_DEVICE_COMPILE__)
+static __constant__ const double RIM_ISERIES[4 * (RIM_ISERIES_NMAX + 1)] = RIM_ISERIES_TABLE;
+#else
+static const double RIM_ISERIES[4 * (RIM_ISERIES_NMAX + 1)] = RIM_ISERIES_TABLE;
+#endif
 
 RIM_DEV double hey_series_order(int j) { return j == 0 ? 2. / 3. : j == 1 ? -2. / 3. : j == 2 ? 1. / 3. : -1. / 3.; }
 
-RIM_DEV void hey_series_table_entry(int j, int k, double *entry)
-{
-    const double nu = hey_series_order(j);
-    const double b = k * (k + nu);
-    entry[0] = b;
-    entry[1] = 1. / b;
-}
+// Device: the rows of a block are fetched by the scalar unit right where they are used (s_load_dwordx16 / x8 into SGPRs,
+// which v_fma_f64 reads as its scalar operand) -- spelled as volatile inline assembly because LLVM otherwise hoists the
+// 100 loop-invariant loads to the top of the kernel and parks them in VGPR lanes (v_writelane / v_readlane: two vector
+// instructions per constant, measured on the first build of this function).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double rim_d4 __attribute__((ext_vector_type(4)));
+typedef double rim_d8 __attribute__((ext_vector_type(8)));
+#define RIM_ISERIES_FMA4(r) do { s0 = rim_fma_k(s0, q, (r).x); s1 = rim_fma_k(s1, q, (r).y); s2 = rim_fma_k(s2, q, (r).z); s3 = rim_fma_k(s3, q, (r).w); } while (0)
+// rows k, k - 1, k - 2 (12 consecutive doubles from row k - 2)
+#define RIM_ISERIES_ROWS3(k) do { \
+        rim_d8 lo_; rim_d4 hi_; \
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=&s"(lo_), "=&s"(hi_) : "s"(tab), "n"(32 * ((k) - 2)), "n"(32 * ((k) - 2) + 64)); \
+        RIM_ISERIES_FMA4(hi_); \
+        { const rim_d4 r_ = { lo_.s4, lo_.s5, lo_.s6, lo_.s7 }; RIM_ISERIES_FMA4(r_); } \
+        { const rim_d4 r_ = { lo_.s0, lo_.s1, lo_.s2, lo_.s3 }; RIM_ISERIES_FMA4(r_); } \
+    } while (0)
+// rows 3, 2, 1, 0
+#define RIM_ISERIES_ROWS4_BASE() do { \
+        rim_d8 lo_, hi_; \
+        asm volatile("s_load_dwordx16 %0, %2, 0\n\ts_load_dwordx16 %1, %2, 64\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=&s"(lo_), "=&s"(hi_) : "s"(tab)); \
+        { const rim_d4 r_ = { hi_.s4, hi_.s5, hi_.s6, hi_.s7 }; RIM_ISERIES_FMA4(r_); } \
+        { const rim_d4 r_ = { hi_.s0, hi_.s1, hi_.s2, hi_.s3 }; RIM_ISERIES_FMA4(r_); } \
+        { const rim_d4 r_ = { lo_.s4, lo_.s5, lo_.s6, lo_.s7 }; RIM_ISERIES_FMA4(r_); } \
+        { const rim_d4 r_ = { lo_.s0, lo_.s1, lo_.s2, lo_.s3 }; RIM_ISERIES_FMA4(r_); } \
+    } while (0)
+#else
+#define RIM_ISERIES_STEP(k) do { s0 = rim_fma(s0, q, tab[4 * (k)]); s1 = rim_fma(s1, q, tab[4 * (k) + 1]); \
+                                 s2 = rim_fma(s2, q, tab[4 * (k) + 2]); s3 = rim_fma(s3, q, tab[4 * (k) + 3]); } while (0)
+#define RIM_ISERIES_ROWS3(k) do { RIM_ISERIES_STEP(k); RIM_ISERIES_STEP((k) - 1); RIM_ISERIES_STEP((k) - 2); } while (0)
+#define RIM_ISERIES_ROWS4_BASE() do { RIM_ISERIES_STEP(3); RIM_ISERIES_STEP(2); RIM_ISERIES_STEP(1); RIM_ISERIES_STEP(0); } while (0)
+#endif
+#define RIM_ISERIES_BLOCK(qmin, k) if (q >= (qmin)) { RIM_HIT(31); RIM_ISERIES_ROWS3(k); }
 
-// The first RIM_SERIES_LDS entries of each order's row are also kept in the wave's LDS (lrow; layout [0 .. RIM_SERIES_LDS + 2]
-// pairs, entry 0 unused, the last two padding for the one-pair-ahead read): one global load per term with a full wait in
-// between left the wave stalled for most of each iteration (the Faraday kernel was 75 % VALU-busy).  LDS reads are
-// prefetched one pair of terms ahead.  Series longer than that (rare: g close to 10) continue from the global table.
-// Host builds pass a table with the same layout.
-#define RIM_SERIES_LDS 20
-#define RIM_SERIES_LDS_ROW (2 * (RIM_SERIES_LDS + 3))
-
-RIM_DEV double ascending_series_tab(const double *lrow, const double *row, double q, double sign)
+// tab: the address of RIM_ISERIES as hey_consts() hands it out (an opaque scalar register pair on the device)
+RIM_DEV void rim_iseries4(const double *tab, double q, double out[4])
 {
-    // Terms are added two at a time, each the previous one times q times the tabulated reciprocal of k (k + nu), and the
-    // series ends after the first PAIR whose second term is below 1e-17 of the sum (the deterministic oracle does the
-    // same; the literal one divides term by term and tests after each).  4 vector instructions per term instead of 7.
-    double term = 1., sum = 1.;
-    const double sq = sign * q;
-    double c1 = lrow[3], c2 = lrow[5];
-    int k = 1;
-    for (; k <= RIM_SERIES_LDS; k += 2) {
-        RIM_HIT(31);
-        const double n1 = lrow[2 * k + 5], n2 = lrow[2 * k + 7];      // the next pair's reciprocals, in flight during this pair
-        term = term * (sq * c1);
-        sum = sum + term;
-        term = term * (sq * c2);
-        sum = sum + term;
-        if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) return sum;
-        c1 = n1;
-        c2 = n2;
-    }
-    for (; k <= RIM_SERIES_TERMS; k += 2) {
-        RIM_HIT(31);
-        term = term * (sq * row[2 * k + 1]);
-        sum = sum + term;
-        term = term * (sq * row[2 * k + 3]);
-        sum = sum + term;
-        if (rim_fabs(term) < 1e-17 * rim_fabs(sum)) break;
-    }
-    return sum;
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q21, 24)
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q18, 21)
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q15, 18)
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q12, 15)
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q9, 12)
+    RIM_ISERIES_BLOCK(RIM_ISERIES_Q6, 9)
+    RIM_ISERIES_ROWS3(6);
+    RIM_ISERIES_ROWS4_BASE();
+    out[0] = s0; out[1] = s1; out[2] = s2; out[3] = s3;
 }
 
 RIM_DEV double bessel_jnu(double nu, double x)
@@ -172,43 +184,17 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
     *ym1 = want_ym1 ? (cs[1] * j1 - r[3]) / sn[1] : 0.;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
-// host builds (CPU tests, wavefront emulator): the table in static storage, filled on first use
-inline const double *hey_series_table_host()
-{
-    static double tab[4 * RIM_SERIES_ROW];
-    static bool ready = false;
-    if (!ready) {
-        for (int j = 0; j < 4; j++)
-            for (int k = 1; k <= RIM_SERIES_TERMS; k++) hey_series_table_entry(j, k, tab + j * RIM_SERIES_ROW + 2 * k);
-        ready = true;
-    }
-    return tab;
-}
-inline const double *hey_series_lds_table_host()
-{
-    static double ltab[4 * RIM_SERIES_LDS_ROW];
-    static bool ready = false;
-    if (!ready) {
-        const double *tab = hey_series_table_host();
-        for (int j = 0; j < 4; j++)
-            for (int i = 0; i < RIM_SERIES_LDS_ROW; i++) ltab[j * RIM_SERIES_LDS_ROW + i] = tab[j * RIM_SERIES_ROW + i];
-        ready = true;
-    }
-    return ltab;
-}
-#endif
-
-// Per-task constants: the series divisor table.
-struct HeyConsts { const double *tab; const double *ltab; };
-
-// series_tab: the global table; lds_tab: the wave's LDS copy of its head ([4][RIM_SERIES_LDS_ROW], filled by
-// hey_series_lds_fill) or, on the host, a table with that layout
-RIM_DEV HeyConsts hey_consts(const double *series_tab, const double *lds_tab)
+// Per-wave constants of the Faraday elements: the address of the series coefficient table.  On the device it is passed
+// through an empty volatile asm once, so that the compiler keeps it in a scalar register pair across the quadrature loops
+// instead of re-deriving the constant address (s_getpc + a GOT load and its wait) in front of every block of terms.
+struct HeyConsts { const double *iser; };
+RIM_DEV HeyConsts hey_consts()
 {
     HeyConsts c;
-    c.tab = series_tab;
-    c.ltab = lds_tab;
+    c.iser = RIM_ISERIES;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(c.iser));
+#endif
     return c;
 }
 
@@ -222,11 +208,10 @@ RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
     double pref[4];
     rim_third_powers(h, pref);
     pref[0] *= RIM_RGAMMA_5_3; pref[1] *= RIM_RGAMMA_1_3; pref[2] *= RIM_RGAMMA_4_3; pref[3] *= RIM_RGAMMA_2_3;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma nounroll
-#endif
+    double ser[4];
+    rim_iseries4(hc.iser, hsq, ser);
     for (int j = 0; j < 4; j++)
-        out[j] = pref[j] * ascending_series_tab(hc.ltab + j * RIM_SERIES_LDS_ROW, hc.tab + j * RIM_SERIES_ROW, hsq, 1.);
+        out[j] = pref[j] * ser[j];
 }
 
 // Observer data of one Faraday coefficient (wave-uniform)

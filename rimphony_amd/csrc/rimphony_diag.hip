@@ -363,36 +363,29 @@ static __device__ HeyPoint hey_point_of(const PointArgs &pa)
 }
 
 template <int KIND>
-__global__ void hey_element_kernel(PointArgs pa, const double *norm_ptr, const double *series_tab, int qr, size_t count,
+__global__ void hey_element_kernel(PointArgs pa, const double *norm_ptr, int qr, size_t count,
                                    const double *fixed, const double *v, double *out)
 {
-    __shared__ double s_ser[4 * RIM_SERIES_LDS_ROW];
-    for (int k = threadIdx.x; k < 4 * RIM_SERIES_LDS_ROW; k += blockDim.x)
-        s_ser[k] = series_tab[(k / RIM_SERIES_LDS_ROW) * RIM_SERIES_ROW + k % RIM_SERIES_LDS_ROW];
-    __syncthreads();
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const HeyPoint pt = hey_point_of(pa);
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
     dist_prepare<KIND>(d, norm_ptr[0]);
-    const HeyConsts hc = hey_consts(series_tab, s_ser);
+    const HeyConsts hc = hey_consts();
     out[i] = hey_element<KIND>(pt, d, hc, qr != 0, fixed[i], v[i]);
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const double *norm_ptr, const double *series_tab, int qr,
+__global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const double *norm_ptr, int qr,
                                                        size_t count, const double *u, double *out, double *spill_base)
 {
     __shared__ double s_tab[96];
     __shared__ double s_inner[RIM_ISTORE_DOUBLES(CAP_INNER)];
-    __shared__ double s_ser[4 * RIM_SERIES_LDS_ROW];
     __shared__ QagParkBase s_qpark;
     const GKLane g = gk_lane_init(s_tab);
     const IStore inner = istore_carve(s_inner, CAP_INNER, spill_base + (size_t) blockIdx.x * SPILL_DOUBLES_PER_WAVE, SPILL_INNER);
     if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
-    for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64)
-        s_ser[i] = series_tab[(i / RIM_SERIES_LDS_ROW) * RIM_SERIES_ROW + i % RIM_SERIES_LDS_ROW];
     __syncthreads();
     HeyPoint pt = hey_point_of(pa);
     pt.s = uni(pt.s); pt.sin_th = uni(pt.sin_th); pt.cos_th = uni(pt.cos_th);
@@ -400,7 +393,7 @@ __global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const doubl
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
     dist_prepare<KIND>(d, norm_ptr[0]);
-    const HeyConsts hc = hey_consts(series_tab, s_ser);
+    const HeyConsts hc = hey_consts();
     for (size_t i = blockIdx.x; i < count; i += gridDim.x) {
         int st = 0;
         const double val = hey_eval_request<KIND>(pt, d, hc, g, inner, &s_qpark, uni(u[i]), qr, st);
@@ -408,7 +401,6 @@ __global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const doubl
     }
 }
 
-const double *rim_ctx_series(const rimphony_ctx *c);
 
 extern "C" int rimphony_hey_element_batch_device(rimphony_ctx *c, int kind, const double *params, int stokes, double s, double theta,
                                                  int qr, size_t count, const double *d_fixed, const double *d_v, double *d_out,
@@ -425,10 +417,10 @@ extern "C" int rimphony_hey_element_batch_device(rimphony_ctx *c, int kind, cons
     const double *norm = rim_ctx_norm(c);
     const dim3 grid((unsigned) ((count + 63) / 64)), block(64);
     switch (kind) {
-    case 0: hipLaunchKernelGGL(hey_element_kernel<0>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
-    case 1: hipLaunchKernelGGL(hey_element_kernel<1>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
-    case 2: hipLaunchKernelGGL(hey_element_kernel<2>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
-    default: hipLaunchKernelGGL(hey_element_kernel<3>, grid, block, RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_fixed, d_v, d_out); break;
+    case 0: hipLaunchKernelGGL(hey_element_kernel<0>, grid, block, RIM_DYN_LDS, st, pa, norm, qr, count, d_fixed, d_v, d_out); break;
+    case 1: hipLaunchKernelGGL(hey_element_kernel<1>, grid, block, RIM_DYN_LDS, st, pa, norm, qr, count, d_fixed, d_v, d_out); break;
+    case 2: hipLaunchKernelGGL(hey_element_kernel<2>, grid, block, RIM_DYN_LDS, st, pa, norm, qr, count, d_fixed, d_v, d_out); break;
+    default: hipLaunchKernelGGL(hey_element_kernel<3>, grid, block, RIM_DYN_LDS, st, pa, norm, qr, count, d_fixed, d_v, d_out); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;
@@ -450,10 +442,10 @@ extern "C" int rimphony_hey_outer_batch_device(rimphony_ctx *c, int kind, const 
     if (rc) return rc;
     const double *norm = rim_ctx_norm(c);
     switch (kind) {
-    case 0: hipLaunchKernelGGL(hey_outer_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
-    case 1: hipLaunchKernelGGL(hey_outer_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
-    case 2: hipLaunchKernelGGL(hey_outer_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
-    default: hipLaunchKernelGGL(hey_outer_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, rim_ctx_series(c), qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    case 0: hipLaunchKernelGGL(hey_outer_kernel<0>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    case 1: hipLaunchKernelGGL(hey_outer_kernel<1>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    case 2: hipLaunchKernelGGL(hey_outer_kernel<2>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, qr, count, d_u, d_out, rim_ctx_spill(c)); break;
+    default: hipLaunchKernelGGL(hey_outer_kernel<3>, dim3(grid), dim3(64), RIM_DYN_LDS, st, pa, norm, qr, count, d_u, d_out, rim_ctx_spill(c)); break;
     }
     HIP_TRY(hipGetLastError());
     return RIMPHONY_OK;

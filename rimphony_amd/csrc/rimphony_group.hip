@@ -59,15 +59,10 @@ struct HeyGroupProblem {
     typedef HeyTask Task;
     typedef GroupParkBase Park;
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
-    enum : int { QUEUE = 4, TAIL_WORD = 15, STATS_WORD = 10, WAVES = RIM_HEY_GROUP_WAVES, EXTRA_LDS_DOUBLES = 4 * RIM_SERIES_LDS_ROW };
+    enum : int { QUEUE = 4, TAIL_WORD = 15, STATS_WORD = 10, WAVES = RIM_HEY_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1 };
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
-        for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64) {
-            const int j = i / RIM_SERIES_LDS_ROW, r = i % RIM_SERIES_LDS_ROW;
-            extra_lds[i] = a.series_tab[j * RIM_SERIES_ROW + r];
-        }
-        __syncthreads();
-        c.hc = hey_consts(a.series_tab, extra_lds);
+        c.hc = hey_consts();
         c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.stokes = STOKES_Q;
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned, Ctx &c, double &norm)

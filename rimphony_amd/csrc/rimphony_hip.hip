@@ -150,16 +150,10 @@ struct HeyvaertsProblem {
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
     typedef HeyTask Task;
     typedef QagParkBase Park;
-    // 5 waves per SIMD = 20 workgroups per CU leave 8 KB of LDS per wave: room for the head of the series divisor table
-    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 4 * RIM_SERIES_LDS_ROW };
+    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 1 };
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
-        for (int i = threadIdx.x; i < 4 * RIM_SERIES_LDS_ROW; i += 64) {
-            const int j = i / RIM_SERIES_LDS_ROW, r = i % RIM_SERIES_LDS_ROW;
-            extra_lds[i] = a.series_tab[j * RIM_SERIES_ROW + r];
-        }
-        __syncthreads();
-        c.hc = hey_consts(a.series_tab, extra_lds);
+        c.hc = hey_consts();
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     {
@@ -611,15 +605,6 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     }
 }
 
-__global__ void series_table_kernel(double *tab)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4 * (RIM_SERIES_TERMS + 1)) return;
-    const int j = i / (RIM_SERIES_TERMS + 1), k = i % (RIM_SERIES_TERMS + 1);
-    if (k == 0) { tab[j * RIM_SERIES_ROW] = 0.; tab[j * RIM_SERIES_ROW + 1] = 0.; return; }
-    hey_series_table_entry(j, k, tab + j * RIM_SERIES_ROW + 2 * k);
-}
-
 __global__ void board_init_kernel(unsigned *flags, unsigned active)
 {
     const unsigned i = threadIdx.x;
@@ -807,7 +792,6 @@ struct rimphony_ctx {
     hipEvent_t ev_start, ev_stop;   // Symphony launch
     int ev_valid;
     hipEvent_t ev_fstart, ev_fstop; // Faraday launch
-    double *d_series;               // Heyvaerts series divisor table (dev_heyvaerts.h)
     int evf_valid;
     // diagnostics: heartbeat words in host-mapped memory
     unsigned long long *hb_host;
@@ -904,7 +888,6 @@ static int take_device_lock(int device, int *fd_out)
 static void ctx_free(rimphony_ctx *c)
 {
     if (c->d_queue) (void) hipFree(c->d_queue);
-    if (c->d_series) (void) hipFree(c->d_series);
     if (c->d_norm) (void) hipFree(c->d_norm);
     if (c->d_perm) (void) hipFree(c->d_perm);
     if (c->d_spill) (void) hipFree(c->d_spill);
@@ -972,8 +955,6 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
         ctx_free(c);
         return RIMPHONY_EHIP;
     }
-    if (hipMalloc(&c->d_series, 4 * RIM_SERIES_ROW * sizeof(double)) != hipSuccess) { ctx_free(c); return RIMPHONY_ENOMEM; }
-    hipLaunchKernelGGL(series_table_kernel, dim3((4 * (RIM_SERIES_TERMS + 1) + 255) / 256), dim3(256), 0, (hipStream_t) 0, c->d_series);
     if (hipDeviceSynchronize() != hipSuccess) { ctx_free(c); return RIMPHONY_EHIP; }
     *out = c;
     return RIMPHONY_OK;
@@ -1322,7 +1303,6 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
         HIP_TRY(hipGetLastError());
         a.perm = c->d_perm;
     }
-    a.series_tab = c->d_series;
     a.heartbeat = c->hb_dev;
     a.hb_task = c->hb_task;
     a.work = (unsigned long long *) d_work;
@@ -1815,7 +1795,6 @@ int rim_wave_grid(rimphony_ctx *c, size_t count, int waves_per_cu, unsigned *gri
     return ensure_spill(c, *grid);
 }
 const double *rim_ctx_norm(const rimphony_ctx *c) { return c->d_norm; }
-const double *rim_ctx_series(const rimphony_ctx *c) { return c->d_series; }
 double *rim_ctx_spill(const rimphony_ctx *c) { return c->d_spill; }
 
 extern "C" int rimphony_gamma_integral_batch_device(rimphony_ctx *c, int kind, const double *params,

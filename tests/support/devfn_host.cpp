@@ -32,7 +32,7 @@ double devh_hey_element(int kind, int stokes, double s, double cos_th, double si
     pt.stokes = stokes;
     DistParams d;
     for (int i = 0; i < 5; i++) d.par[i] = par[i];
-    const HeyConsts hc = hey_consts(hey_series_table_host(), hey_series_lds_table_host());
+    const HeyConsts hc = hey_consts();
     switch (kind) {
     case 0: dist_prepare<0>(d, norm); return hey_element<0>(pt, d, hc, qr != 0, fixed, v);
     case 1: dist_prepare<1>(d, norm); return hey_element<1>(pt, d, hc, qr != 0, fixed, v);

@@ -53,7 +53,7 @@ static void lane_body(EmuTask *t)
         HeyPoint hp;
         hp.s = pt.s; hp.sin_th = pt.sin_th; hp.cos_th = pt.cos_th;
         hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = t->stokes;
-        const HeyConsts hc = hey_consts(hey_series_table_host(), hey_series_lds_table_host());
+        const HeyConsts hc = hey_consts();
         val = heyvaerts_coefficient<KIND>(hp, d, hc, g, inner, outer, &s_hpark, &s_qpark, st);
     } else {
         val = symphony_coefficient<KIND>(pt, d, g, inner, outer, &s_park, &s_qpark, st);
@@ -252,7 +252,7 @@ static void hey_group_lane_body(EmuGroupTask *t)
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = t->par[k];
     dist_prepare<KIND>(d, t->norm);
-    const HeyConsts hc = hey_consts(hey_series_table_host(), hey_series_lds_table_host());
+    const HeyConsts hc = hey_consts();
     double vals[RIM_GROUP] = { 0, 0, 0, 0 };
     int stats[RIM_GROUP] = { 0, 0, 0, 0 };
     heyvaerts_group<KIND>(hp, d, hc, t->slots, t->nmem, g, s_ginner, s_spill,

@@ -2,7 +2,9 @@
 """A/B of two builds of the library on the SAME GPU box (wall time differs by up to ~10 % between MI355X devices, so
 builds must never be compared across gpurun calls).  Each build runs in its own child process (the library path is
 read at import); alternating order, best of `reps`.
-usage: ab_libs.py LIB_A LIB_B [config] [rows] [mask] [reps]"""
+usage: ab_libs.py LIB_A LIB_B [config] [rows] [mask] [reps]
+AB_ALLOW_DIFF=1: the two builds are DIFFERENT computations on purpose (a lock-step reformulation that changes a rounding
+in kernels and oracle together): report the ratio, say that the tables differ, exit 0."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 a, b = sys.argv[1], sys.argv[2]
@@ -43,7 +45,9 @@ for lib in (a, b):
     print("%-40s kernel ms %s   output md5 %s" % (os.path.basename(lib), " ".join("%.1f" % m for m, _ in res[lib]), res[lib][0][1]))
 md5s = {m for lib in (a, b) for _, m in res[lib]}
 print("ratio B/A (best of %d): %.4f   outputs identical: %s" % (reps, min(m for m, _ in res[b]) / min(m for m, _ in res[a]), len(md5s) == 1))
-if len(md5s) != 1:
+if len(md5s) != 1 and os.environ.get("AB_ALLOW_DIFF") == "1":
+    print("tables differ (md5 %s): allowed, AB_ALLOW_DIFF=1" % " / ".join(sorted(md5s)))
+elif len(md5s) != 1:
     # a build that moves a bit is not a faster version of the same computation: this tool must not report it as one
     print("FAIL: the tables of the two builds differ (md5 %s)" % " / ".join(sorted(md5s)))
     sys.exit(2)

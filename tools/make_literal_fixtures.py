@@ -12,7 +12,13 @@ CPU only; run in the build container:  python tools/make_literal_fixtures.py [th
 arithmetic.  out_rev: the literal flavour with the GK31 terms added in the opposite order (oracle `make controls`,
 liboracle_libm_rev.so); out_fma: the literal flavour compiled with -ffp-contract=fast (liboracle_libm_fma.so).  Both are
 equally legitimate evaluations of the reference's formulas; the distance literal <-> control is what "agreement with
-the Rust/GSL binary" can mean at best, and bench.py prints it next to the HIP <-> literal distance (`parity.control`)."""
+the Rust/GSL binary" can mean at best, and bench.py prints it next to the HIP <-> literal distance (`parity.control`).
+
+--faraday-only (round 4): recompute slots rho_Q / rho_V of `out`, `out_rev` and `out_fma` of the eight-coefficient files
+and splice them in (the Symphony slots do not go through the functions that changed).  Round 4 replaced the literal
+flavour's Gamma function -- exp(lgamma(w)) / prod, 15 to 27 ulp off at the four arguments the quasi-resonant elements
+need -- by the C library's long double Gamma (oracle/rimo_heyvaerts.c rimo_gamma_real); the previous Faraday columns
+are kept in the files as `out_r3_gamma_explgamma` for the record."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -22,10 +28,34 @@ from rimphony_amd import workload
 
 CASES = [("cfg2_powerlaw_jI_aI", 0, 8192), ("cfg2_powerlaw_8", 1000000, 2048), ("cfg3_thermal_8", 0, 2048),
          ("cfg4_pitchypl_8", 0, 2048), ("cfg5_pitchykappa_8", 0, 2048)]
-argv = [a for a in sys.argv[1:] if a != "--controls"]
+argv = [a for a in sys.argv[1:] if a not in ("--controls", "--faraday-only")]
 controls = "--controls" in sys.argv
+faraday_only = "--faraday-only" in sys.argv
 threads = int(argv[0]) if argv else 8
 only = argv[1:] or None
+if faraday_only:
+    import ctypes, subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all", "controls"], check=True, stdout=subprocess.DEVNULL)
+    for cfg, start, n in CASES:
+        if (only and cfg not in only) or cfg == "cfg2_powerlaw_jI_aI":
+            continue
+        path = os.path.join(ROOT, "tests", "golden", "literal_%s.npz" % cfg)
+        z = dict(np.load(path))
+        kind, mask, s, th, params = workload.make_batch(cfg, n, start=start)
+        if "out_r3_gamma_explgamma" not in z:
+            z["out_r3_gamma_explgamma"] = z["out"][:, 6:8].copy()
+        for key, lib in (("out", "liboracle_libm.so"), ("out_rev", "liboracle_libm_rev.so"), ("out_fma", "liboracle_libm_fma.so")):
+            L = ctypes.CDLL(os.path.join(ROOT, "oracle", lib))
+            L.rimo_batch.restype = ctypes.c_int
+            L.rimo_batch.argtypes = oracle_bind.load("libm").rimo_batch.argtypes
+            L.rimo_build_flavour.restype = ctypes.c_char_p
+            t0 = time.time()
+            far = oracle_bind.batch(L, kind, s, th, params, 0xC0, nthreads=threads)
+            z[key] = z[key].copy()
+            z[key][:, 6:8] = far[:, 6:8]
+            print("%s %s (%s): Faraday slots of %d rows in %.0f s" % (cfg, key, L.rimo_build_flavour().decode(), n, time.time() - t0), flush=True)
+        np.savez_compressed(path, **z)
+    sys.exit(0)
 if controls:
     import ctypes, subprocess
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "controls"], check=True, stdout=subprocess.DEVNULL)
