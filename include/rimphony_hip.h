@@ -83,18 +83,20 @@ int rimphony_dist_nparams(int dist_kind);   /* 4, 1, 5, 4; negative for an unkno
 #define RIMPHONY_ENOMEM    -3
 #define RIMPHONY_ENODEVICE -4
 #define RIMPHONY_EBUSY     -5   /* RIMPHONY_EXCLUSIVE=1 and another context already has the device */
-#define RIMPHONY_ENOTSUP   -6   /* e.g. a `precision` this build does not implement */
+#define RIMPHONY_ENOTSUP   -6   /* e.g. a `precision` this build does not implement; librccl not loadable */
+#define RIMPHONY_ERCCL     -7   /* an RCCL call failed (rimphony_last_error() has RCCL's text) */
 
 /* `precision` of the _ex / _multi entry points.  F64 is the reference's arithmetic (bit-identical to the
- * oracle).  F32_INTEGRAND (BASELINE configs[4]) evaluates the bodies of the elementary functions of the Symphony
- * integrand -- the exponential of a reduced argument, the logarithm of a mantissa, the Debye cube root -- in single
- * precision on the hardware transcendental unit, with every difference, every product with the harmonic number and
- * every quadrature sum in fp64; it applies to the six Symphony slots (the Faraday pair is always fp64) and carries
- * no parity claim: ~1e-8 median, ~1e-6 p99 relative difference from F64, 0.90 (power law) / 0.96 (thermal) of the fp64
- * kernel time.  It is offered for RIMPHONY_POWER_LAW and RIMPHONY_THERMAL_JUETTNER only: for the
- * anisotropic distributions (PITCHY_PL, PITCHY_KAPPA -- the one BASELINE configs[4] names) it was measured 1.53 x SLOWER
- * than fp64 with 1.9 % new NaNs, because its non-smooth 1e-7 noise trips GSL's round-off detectors on integrals that
- * cancel; those kinds return RIMPHONY_ENOTSUP, as does any other `precision` value. */
+ * oracle) and the only precision offered.  F32_INTEGRAND (BASELINE configs[4]: the bodies of the elementary functions of
+ * the Symphony integrand in single precision on the hardware transcendental unit, every difference, every product with
+ * the harmonic number and every quadrature sum in fp64) returns RIMPHONY_ENOTSUP for EVERY distribution, as does any
+ * other value: measured, it is slower AND lossier than F64 -- on pitchy_kappa (the distribution configs[4] names) 1.53 x
+ * the fp64 time with 1.9 % new NaNs, because its non-smooth 1e-7 noise trips GSL's round-off detectors on integrals that
+ * cancel; on the power-law and thermal distributions 0.90 / 0.96 of the fp64 time of the round-2 kernel it is built on,
+ * i.e. 1.36 / 1.43 x the time of the fp64 default since that moved to the group kernel (round 3), with ~1e-6 p99
+ * differences.  The kernels stay in the library behind a measurement hook -- a context created with
+ * RIMPHONY_F32_VARIANT=1 in the environment accepts F32_INTEGRAND for POWER_LAW and THERMAL_JUETTNER
+ * (tools/f32_variant.py) -- so that the statement above can be re-measured; configs[4]'s table itself runs in F64. */
 #define RIMPHONY_PRECISION_F64            0
 #define RIMPHONY_PRECISION_F32_INTEGRAND  1
 
@@ -118,6 +120,7 @@ typedef struct rimphony_ctx rimphony_ctx;
 int rimphony_ctx_create(int device, rimphony_ctx **out);
 void rimphony_ctx_destroy(rimphony_ctx *ctx);
 int rimphony_ctx_shared_mode(const rimphony_ctx *ctx);   /* 0: owns the device, 1: shared mode */
+int rimphony_ctx_device(const rimphony_ctx *ctx, int *device);   /* the HIP device the context is bound to */
 const char *rimphony_strerror(int code);
 /* Text of the most recent failure on the calling thread (which HIP call failed and why); "" if none.  The library
  * never prints. */
@@ -140,7 +143,7 @@ int rimphony_last_work(rimphony_ctx *ctx, rimphony_work *out);
 /* The tail of the most recent batch call (device-side, read back synchronously).  Per-task cost has a heavy tail and the
  * reference's chunk marching is sequential: the task with the longest CHAIN of batches (each waits for its slowest
  * gamma-integral / inner integral) bounds how early a launch can end, whatever the cooperative tail spreads out.
- *   out[0], out[1]   Symphony: batches of the heaviest coefficient, and its row
+ *   out[0], out[1]   Symphony: batches of the heaviest coefficient, and its row (rows to 2^40)
  *   out[2], out[3]   Faraday: the same
  *   out[4]           Symphony group kernel: passes the coefficients would have executed one by one (out[4] / passes of
  *                    rimphony_last_work = how many coefficients an executed pass served on average)
@@ -164,7 +167,9 @@ int rimphony_last_faraday_ms(rimphony_ctx *ctx, float *ms);
  * [6] n_start bits, [7] delta_n bits, [8] lane of the running gamma-integral,
  * [9] its n (bits), [10] 1 when the task has finished.  Tasks of the Heyvaerts kernel
  * are addressed as task | (1 << 62).  Symphony tasks are watched in the one-wave-per-coefficient kernel only
- * (RIMPHONY_SYM_SOLO=1 when the context is created); the group kernel does not write heartbeats. */
+ * (RIMPHONY_SYM_SOLO=1 when the context is created); the group kernel does not write heartbeats, so for a Symphony
+ * task of a context without that setting the call returns RIMPHONY_ENOTSUP instead of handing out words that would
+ * never change. */
 int rimphony_debug_heartbeat(rimphony_ctx *ctx, uint64_t task, uint64_t **host_words);
 
 /* Diagnostics: the 16 raw device counter words of the most recent batch call: [0] task head,
@@ -216,6 +221,39 @@ int rimphony_batch_compute_ex(rimphony_ctx *ctx, int dist_kind, size_t n,
 int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx, int dist_kind, size_t n,
                                  const double *s, const double *theta, const double *const *params,
                                  uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work);
+
+/* The same with DEVICE buffers: ctxs[r] (bound to its own device) evaluates the n_local[r] rows its arrays hold --
+ * d_s[r], d_theta[r], d_params[r][k], d_out[r] ([n_local[r]][8]), optionally d_status[r], d_work[r], on streams[r] (or the
+ * null stream if `streams` is NULL).  All launches are issued from the calling thread before anything is waited for; with
+ * `synchronize` != 0 the call returns when every device has finished, otherwise it is asynchronous on the given streams.
+ * Which rows a context holds is the caller's choice; rimphony_rccl_gather_table assumes the interleaved convention
+ * (row i of the table on rank i mod world).  Replaces N concurrent calls of lib.rs:178-191's loop body. */
+int rimphony_batch_compute_multi_device(rimphony_ctx *const *ctxs, int n_ctx, int dist_kind, const size_t *n_local,
+                                        const double *const *d_s, const double *const *d_theta,
+                                        const double *const *const *d_params, uint32_t coeff_mask, int precision,
+                                        double *const *d_out, int32_t *const *d_status, uint64_t *const *d_work,
+                                        void *const *streams, int synchronize);
+
+/* The one collective of the path, for a host that is not Python (north_star: "RCCL gather over xGMI for the output
+ * table"; the Python form is rimphony_amd/sharding.py).  librccl.so.1 is dlopen'ed on the first of these calls
+ * (RIMPHONY_RCCL_LIB overrides the name); the library does not link against it.  One process per GPU:
+ *   rimphony_rccl_available()        1 if librccl could be loaded, else 0 (rimphony_last_error() says why)
+ *   rimphony_rccl_unique_id(id)      rank 0: fill 128 bytes, to be handed to the other ranks by the caller's own means
+ *   rimphony_rccl_comm_create(..)    ncclCommInitRank on the context's device; *comm is an ncclComm_t
+ *   rimphony_rccl_gather_table(..)   every rank: d_shard = its [ceil((n_total - rank) / world)][8] rows of the interleaved
+ *                                    table (device); root: d_table [n_total][8] (device) receives row i from rank i mod
+ *                                    world.  One grouped send / receive per rank (the root sends to itself too, so a world
+ *                                    of one runs the same RCCL calls) and an un-interleave kernel, all on `stream`.
+ *                                    d_scratch: n_total * 8 doubles on the root (ignored elsewhere); NULL = allocated
+ *                                    and freed inside, and the call then returns synchronised.
+ *   rimphony_rccl_comm_destroy(comm)
+ * A comm created elsewhere (the caller's own RCCL binding) is accepted as well: it is only passed through. */
+int rimphony_rccl_available(void);
+int rimphony_rccl_unique_id(void *id128);
+int rimphony_rccl_comm_create(rimphony_ctx *ctx, int rank, int world, const void *id128, void **comm);
+int rimphony_rccl_comm_destroy(void *comm);
+int rimphony_rccl_gather_table(rimphony_ctx *ctx, void *comm, int rank, int world, int root, size_t n_total,
+                               const double *d_shard, double *d_table, double *d_scratch, void *stream);
 
 /* Status histogram of a computed table: hist[slot * 8 + b] = rows whose status word of `slot` has bit b set
  * (b = 0..6, the RIMPHONY_ST_* bits in order), hist[slot * 8 + 7] = rows with status 0.  Synchronous. */

@@ -115,6 +115,8 @@ double rimo_gamma_real(double z);
 double rimo_bessel_i(double nu, double x);     /* x.besseli(nu)  */
 double rimo_bessel_jnu(double nu, double x);   /* x.besselj(nu), ascending series (small x) */
 double rimo_bessel_ynu(double nu, double x);   /* x.bessely(nu), reflection formula */
+/* { J_sigma, Y_sigma, J_(sigma-1), Y_(sigma-1) } at x as the quasi-resonant elements of this flavour obtain them */
+void rimo_bessel_jy_set(double sigma, double x, double out[4]);
 
 /* --- distributions ----------------------------------------------------- */
 int rimo_dist_init(rimo_dist *d, int kind, const double *params); /* new()+limits+full_calculation(): 0 or GSL status */

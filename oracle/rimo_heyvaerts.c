@@ -151,12 +151,74 @@ double rimo_bessel_ynu(double nu, double x)  /* Y_nu(x) by reflection */
     return (cs * rimo_bessel_jnu(nu, x) - rimo_bessel_jnu(-nu, x)) / sn;
 }
 
+/* J_sigma, Y_sigma, J_(sigma-1), Y_(sigma-1) at x for a non-integer 0 < sigma < 8 as the kernels evaluate them on the J/Y
+ * branch since round 4 (dev_heyvaerts.h bessel_jy_fast, operation for operation): one power h^sigma and two reciprocals for
+ * the four prefactors, rim_rgamma_quad for the four 1 / Gamma, one sincos, the four ascending series in one loop as
+ * numerator / denominator pairs with one division each at the end. */
+static void jy_fast(double sigma, double x, int want_ym1, double *js, double *ys, double *jm1, double *ym1)
+{
+    const double h = 0.5 * x, q = h * h;
+    double ll;
+    const double lh = rim_log_dd(h, &ll);
+    const double p = rim_pow_from_log(lh, ll, sigma);
+    const double hinv = 1. / h, pinv = 1. / p;
+    double rg[4];
+    rim_rgamma_quad(sigma, rg);
+    double sn, cs;
+    rim_sincos(RIM_PI * sigma, &sn, &cs);
+    const double nu0 = sigma, nu1 = sigma - 1., nu2 = -sigma, nu3 = 1. - sigma;
+    double n0 = 1., n1 = 1., n2 = 1., n3 = 1., d0 = 1., d1 = 1., d2 = 1., d3 = 1., pw = 1.;
+    const double mq = -q;
+    int k;
+    for (k = 1; k <= 80; k++) {
+        const double kd = (double) k;
+        pw = pw * mq;
+        const double e0 = kd * (kd + nu0), e1 = kd * (kd + nu1), e2 = kd * (kd + nu2), e3 = kd * (kd + nu3);
+        n0 = rim_fma(n0, e0, pw); d0 = d0 * e0;
+        n1 = rim_fma(n1, e1, pw); d1 = d1 * e1;
+        n2 = rim_fma(n2, e2, pw); d2 = d2 * e2;
+        n3 = rim_fma(n3, e3, pw); d3 = d3 * e3;
+        const double t = m_fabs(pw);
+        if (t < 1e-17 * m_fabs(n0) && t < 1e-17 * m_fabs(n1) && t < 1e-17 * m_fabs(n2) && t < 1e-17 * m_fabs(n3)) break;
+    }
+    if (t_ctr) { t_ctr->hey_series_terms += (uint64_t) (4 * (k <= 80 ? k : 80)); t_ctr->hey_series_calls += 4; }
+    const double j_s = (p * rg[0]) * (n0 / d0);
+    const double j_sm1 = ((p * hinv) * rg[1]) * (n1 / d1);
+    const double j_ms = (pinv * rg[3]) * (n2 / d2);
+    *js = j_s;
+    *jm1 = j_sm1;
+    *ys = (cs * j_s - j_ms) / sn;
+    if (want_ym1) {
+        const double j_1ms = ((h * pinv) * rg[2]) * (n3 / d3);
+        *ym1 = (cs * j_sm1 + j_1ms) / sn;
+    } else {
+        *ym1 = 0.;
+    }
+}
+
+/* the Bessel values of the J/Y branch of a quasi-resonant element (heyvaerts.rs:335-336, 359-363, 437-441) */
+static void jy_set(double sigma, double x, int want_ym1, double *js, double *ys, double *jm1, double *ym1)
+{
+    if (!RIMO_LIT(RIMO_ATTR_JYFAST) && sigma > 0. && sigma < 8. && sigma != rim_floor(sigma)) {
+        jy_fast(sigma, x, want_ym1, js, ys, jm1, ym1);
+        return;
+    }
+    *js = rimo_bessel_jnu(sigma, x);
+    *jm1 = rimo_bessel_jnu(sigma - 1., x);
+    *ys = rimo_bessel_ynu(sigma, x);
+    *ym1 = want_ym1 ? rimo_bessel_ynu(sigma - 1., x) : 0.;
+}
+
+/* test seam: { J_sigma, Y_sigma, J_(sigma-1), Y_(sigma-1) } at x as the elements of this flavour obtain them */
+void rimo_bessel_jy_set(double sigma, double x, double out[4]) { jy_set(sigma, x, 1, out, out + 1, out + 2, out + 3); }
+
 /* ---- the calculation ------------------------------------------------------- */
 
 typedef struct {
     const rimo_dist *d;
     int stokes;
     double s, cos_observer_angle, sin_observer_angle, sigma0, sigma0_sq;
+    double dinv;             /* 1 / (sigma0 sin(theta)): the deterministic flavour multiplies by it, as the kernels do */
     /* set inside integrands */
     double sigma, pomega, x, gamma, mu;
     /* inner integral context */
@@ -170,9 +232,21 @@ static void fill_coord_vars(hey_state *st, double sigma, double pomega)
     st->sigma = sigma;
     st->pomega = pomega;
     st->x = m_sqrt(sigma * sigma - pomega * pomega - st->sigma0_sq);
-    st->gamma = (sigma - pomega * st->cos_observer_angle) / (st->sigma0 * st->sin_observer_angle);
+    if (RIMO_LIT(RIMO_ATTR_DINV))
+        st->gamma = (sigma - pomega * st->cos_observer_angle) / (st->sigma0 * st->sin_observer_angle);
+    else
+        st->gamma = (sigma - pomega * st->cos_observer_angle) * st->dinv;
     st->mu = (sigma * st->cos_observer_angle - pomega)
         / (st->sigma0 * st->sin_observer_angle * m_sqrt(st->gamma * st->gamma - 1.));
+}
+
+/* g of the quasi-resonant elements (heyvaerts.rs:309, 406) */
+static double qr_g(const hey_state *st)
+{
+    if (RIMO_LIT(RIMO_ATTR_GFORM))
+        return SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
+    /* the deterministic flavour, as the kernels (dev_heyvaerts.h hey_shared): one root, and the quotient (sigma - x) / x */
+    return SQRT_8_OVER_3 * (st->sigma - st->x) * m_sqrt((st->sigma - st->x) / st->x);
 }
 
 static double dfdsigma(const hey_state *st)
@@ -180,7 +254,7 @@ static double dfdsigma(const hey_state *st)
     double dfdg, dfdcxi;
     rimo_calc_f_derivatives(st->d, st->gamma, st->mu, &dfdg, &dfdcxi);
 
-    const double g_term = dfdg / (st->sigma0 * st->sin_observer_angle);
+    const double g_term = RIMO_LIT(RIMO_ATTR_DINV) ? dfdg / (st->sigma0 * st->sin_observer_angle) : dfdg * st->dinv;
     double mu_term;
     if (dfdcxi == 0.) {
         mu_term = 0.;
@@ -200,16 +274,18 @@ static double h_qr_element(const hey_state *st)
 {
     const double po_sq = st->pomega * st->pomega;
     const double smxox = (st->sigma - st->x) / st->x;
-    const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
+    const double g = qr_g(st);
     double y;
 
+    double js = 0., ys = 0., jm1 = 0., ym1 = 0.;
+    if (!(g < G_APPROXIMATION_CUTOFF)) jy_set(st->sigma, st->x, 1, &js, &ys, &jm1, &ym1);
     if (g < G_APPROXIMATION_CUTOFF) {
         const double plus = rimo_bessel_i(2. / 3., g);
         const double minus = rimo_bessel_i(-2. / 3., g);
         y = FOUR_OVER_SQRT_27 * (smxox * smxox) * (minus - plus) * (minus + plus);
     } else {
-        const double jvp = rimo_bessel_jnu(st->sigma - 1., st->x) - st->sigma * rimo_bessel_jnu(st->sigma, st->x) / st->x;
-        const double yvp = rimo_bessel_ynu(st->sigma - 1., st->x) - st->sigma * rimo_bessel_ynu(st->sigma, st->x) / st->x;
+        const double jvp = jm1 - st->sigma * js / st->x;
+        const double yvp = ym1 - st->sigma * ys / st->x;
         y = jvp * yvp;
     }
     const double t1 = RIM_PI * RIM_PI * (st->x * st->x) * y;
@@ -219,7 +295,7 @@ static double h_qr_element(const hey_state *st)
         const double minus = rimo_bessel_i(-1. / 3., g);
         y = 0.5 * FOUR_OVER_SQRT_27 * smxox * (minus - plus) * (minus + plus);
     } else {
-        y = -rimo_bessel_jnu(st->sigma, st->x) * rimo_bessel_ynu(st->sigma, st->x);
+        y = -js * ys;
     }
     const double t2 = RIM_PI * RIM_PI * (st->pomega * st->pomega) * y;
 
@@ -248,7 +324,7 @@ static double h_nr_element(const hey_state *st)
 
 static double f_qr_element(const hey_state *st)
 {
-    const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
+    const double g = qr_g(st);
     double y;
     if (g < G_APPROXIMATION_CUTOFF) {
         y = INVERSE_SQRT_3
@@ -256,8 +332,10 @@ static double f_qr_element(const hey_state *st)
             * (rimo_bessel_i(-2. / 3., g) - rimo_bessel_i(2. / 3., g))
             * (rimo_bessel_i(-1. / 3., g) + rimo_bessel_i(1. / 3., g));
     } else {
-        const double jvp = rimo_bessel_jnu(st->sigma - 1., st->x) - st->sigma * rimo_bessel_jnu(st->sigma, st->x) / st->x;
-        y = -st->x * jvp * rimo_bessel_ynu(st->sigma, st->x);
+        double js, ys, jm1, ym1;
+        jy_set(st->sigma, st->x, 0, &js, &ys, &jm1, &ym1);
+        const double jvp = jm1 - st->sigma * js / st->x;
+        y = -st->x * jvp * ys;
     }
     const double dfds = dfdsigma(st);
     return -TWO_PI * INVERSE_C * st->pomega * (RIM_PI * y - 1.) * dfds;
@@ -338,7 +416,7 @@ static double qr_inner_cb(double pomega, void *ctx)
     fill_coord_vars(st, st->fixed, pomega);
     if (st->c) {
         st->c->integrand_evals++;
-        const double g = SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);
+        const double g = qr_g(st);
         if (g < G_APPROXIMATION_CUTOFF) st->c->hey_qr_i_samples++; else st->c->hey_qr_jy_samples++;
     }
     return st->stokes == RIMO_STOKES_Q ? h_qr_element(st) : f_qr_element(st);
@@ -418,6 +496,7 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
     m_sincos(theta, &st.sin_observer_angle, &st.cos_observer_angle);
     st.sigma0 = s * st.sin_observer_angle;
     st.sigma0_sq = st.sigma0 * st.sigma0;
+    st.dinv = 1. / (st.sigma0 * st.sin_observer_angle);
     st.sigma = st.pomega = st.x = st.gamma = st.mu = RIM_NAN;
     st.fixed = RIM_NAN;
     st.ows = rimo_workspace_alloc(4096);
@@ -508,6 +587,7 @@ double rimo_hey_outer_integrand(const rimo_dist *d, int stokes, double s, double
     m_sincos(theta, &st.sin_observer_angle, &st.cos_observer_angle);
     st.sigma0 = s * st.sin_observer_angle;
     st.sigma0_sq = st.sigma0 * st.sigma0;
+    st.dinv = 1. / (st.sigma0 * st.sin_observer_angle);
     st.sigma = st.pomega = st.x = st.gamma = st.mu = RIM_NAN;
     st.fixed = RIM_NAN;
     st.ows = NULL;
@@ -529,6 +609,7 @@ double rimo_hey_element(const rimo_dist *d, int stokes, double s, double theta, 
     m_sincos(theta, &st.sin_observer_angle, &st.cos_observer_angle);
     st.sigma0 = s * st.sin_observer_angle;
     st.sigma0_sq = st.sigma0 * st.sigma0;
+    st.dinv = 1. / (st.sigma0 * st.sin_observer_angle);
     st.fixed = fixed;
     st.c = NULL;
     return qr ? qr_inner_cb(v, &st) : nr_inner_cb(v, &st);

@@ -27,7 +27,10 @@ enum {
     RIMO_ATTR_SINCOS   = 1 << 9,   /* sin / cos from glibc, not rim_sincos */
     RIMO_ATTR_UNFUSED  = 1 << 10,  /* Horner steps a * b + c in two roundings (Leung Bessel: Symphony only) */
     RIMO_ATTR_BESSEL   = 1 << 11,  /* Leung Bessel roots / cube root / region log10 in their literal forms (Symphony only) */
-    RIMO_ATTR_ALL      = (1 << 12) - 1
+    RIMO_ATTR_DINV     = 1 << 12,  /* gamma and the gamma-term of d f / d sigma: divisions by sigma0 sin(theta), not products with its reciprocal */
+    RIMO_ATTR_GFORM    = 1 << 13,  /* g = sqrt(8)/3 (sigma - x)^1.5 / sqrt(x) literally, not sqrt(8)/3 (sigma - x) sqrt((sigma - x) / x) */
+    RIMO_ATTR_JYFAST   = 1 << 14,  /* J/Y branch: four separate pow / Gamma / term-recurrence evaluations, not the joint one (jy_fast) */
+    RIMO_ATTR_ALL      = (1 << 15) - 1
 };
 
 #if defined(RIMO_ATTR)

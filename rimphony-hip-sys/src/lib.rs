@@ -71,6 +71,7 @@ pub const RIMPHONY_ENOMEM: c_int = -3;
 pub const RIMPHONY_ENODEVICE: c_int = -4;
 pub const RIMPHONY_EBUSY: c_int = -5;
 pub const RIMPHONY_ENOTSUP: c_int = -6;
+pub const RIMPHONY_ERCCL: c_int = -7;
 
 pub const RIMPHONY_PRECISION_F64: c_int = 0;
 pub const RIMPHONY_PRECISION_F32_INTEGRAND: c_int = 1;
@@ -81,6 +82,7 @@ extern "C" {
     pub fn rimphony_ctx_create(device: c_int, out: *mut *mut rimphony_ctx) -> c_int;
     pub fn rimphony_ctx_destroy(ctx: *mut rimphony_ctx);
     pub fn rimphony_ctx_shared_mode(ctx: *const rimphony_ctx) -> c_int;
+    pub fn rimphony_ctx_device(ctx: *const rimphony_ctx, device: *mut c_int) -> c_int;
     pub fn rimphony_strerror(code: c_int) -> *const c_char;
     pub fn rimphony_last_error() -> *const c_char;
     pub fn rimphony_version() -> *const c_char;
@@ -114,6 +116,21 @@ extern "C" {
         ctxs: *const *mut rimphony_ctx, n_ctx: c_int, dist_kind: c_int, n: usize,
         s: *const c_double, theta: *const c_double, params: *const *const c_double,
         coeff_mask: u32, precision: c_int, out: *mut c_double, status: *mut i32, work: *mut u64) -> c_int;
+    /// device buffers per context; asynchronous on `streams` unless `synchronize` != 0
+    pub fn rimphony_batch_compute_multi_device(
+        ctxs: *const *mut rimphony_ctx, n_ctx: c_int, dist_kind: c_int, n_local: *const usize,
+        d_s: *const *const c_double, d_theta: *const *const c_double, d_params: *const *const *const c_double,
+        coeff_mask: u32, precision: c_int, d_out: *const *mut c_double, d_status: *const *mut i32,
+        d_work: *const *mut u64, streams: *const *mut c_void, synchronize: c_int) -> c_int;
+    /// RCCL (dlopen'ed by the library): the gather of the interleaved table on a root rank
+    pub fn rimphony_rccl_available() -> c_int;
+    pub fn rimphony_rccl_unique_id(id128: *mut c_void) -> c_int;
+    pub fn rimphony_rccl_comm_create(
+        ctx: *mut rimphony_ctx, rank: c_int, world: c_int, id128: *const c_void, comm: *mut *mut c_void) -> c_int;
+    pub fn rimphony_rccl_comm_destroy(comm: *mut c_void) -> c_int;
+    pub fn rimphony_rccl_gather_table(
+        ctx: *mut rimphony_ctx, comm: *mut c_void, rank: c_int, world: c_int, root: c_int, n_total: usize,
+        d_shard: *const c_double, d_table: *mut c_double, d_scratch: *mut c_double, stream: *mut c_void) -> c_int;
     pub fn rimphony_status_histogram_device(
         ctx: *mut rimphony_ctx, n: usize, d_status: *const i32, hist: *mut u64, stream: *mut c_void) -> c_int;
 

@@ -68,7 +68,8 @@ def build_hip(force=False, verbose=False):
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build librimphony_hip.so")
     cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "rimphony_hip.hip"), os.path.join(CSRC, "rimphony_diag.hip"),
-                                    os.path.join(CSRC, "rimphony_group.hip"), "-o", LIB]
+                                    os.path.join(CSRC, "rimphony_group.hip"), os.path.join(CSRC, "rimphony_multi.hip"),
+                                    "-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=ROOT)

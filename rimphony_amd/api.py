@@ -60,7 +60,7 @@ SLOTS_ALL = 0xFF
 SLOTS_SYMPHONY = 0x3F
 # `precision` of the batch entry points (include/rimphony_hip.h)
 PRECISION_F64 = 0               # the reference's arithmetic; bit-identical to the oracle
-PRECISION_F32_INTEGRAND = 1     # fp32-core elementary functions in the Symphony integrand; no parity claim
+PRECISION_F32_INTEGRAND = 1     # refused by the library (RIMPHONY_ENOTSUP): slower and lossier than F64, include/rimphony_hip.h
 
 
 def slot_of(coeff, stokes):
@@ -403,6 +403,81 @@ def compute_batch_multi(ctxs, kind, s, theta, params, coeff_mask=SLOTS_ALL, want
         work.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)) if want_work else None), "rimphony_batch_compute_multi")
     ret = [out] + ([status] if want_status else []) + ([work] if want_work else [])
     return ret[0] if len(ret) == 1 else tuple(ret)
+
+
+def compute_batch_multi_device(ctxs, kind, shards, coeff_mask=SLOTS_ALL, want_status=False, synchronize=True):
+    """rimphony_batch_compute_multi_device: device buffers per context.  shards[r] = (s, theta, [params...]) as torch
+    tensors on ctxs[r]'s device; returns the per-context [n_r, 8] output tensors (+ status tensors)."""
+    import torch
+    lib = capi.load()
+    n_ctx = len(ctxs)
+    dp = ctypes.POINTER(ctypes.c_double)
+    np_k = NPARAMS[kind]
+    outs, stats, keep = [], [], []
+    n_local = (ctypes.c_size_t * n_ctx)()
+    d_s, d_th, d_out = (ctypes.c_void_p * n_ctx)(), (ctypes.c_void_p * n_ctx)(), (ctypes.c_void_p * n_ctx)()
+    d_par = (ctypes.POINTER(ctypes.c_void_p) * n_ctx)()
+    d_st = (ctypes.c_void_p * n_ctx)()
+    streams = (ctypes.c_void_p * n_ctx)()
+    for r, (c, (s, th, params)) in enumerate(zip(ctxs, shards)):
+        if len(params) != np_k:
+            raise ValueError("distribution kind %d takes %d parameter arrays" % (kind, np_k))
+        n = s.numel()
+        n_local[r] = n
+        out = torch.empty((n, 8), dtype=torch.float64, device=s.device)
+        st = torch.empty((n, 8), dtype=torch.int32, device=s.device) if want_status else None
+        arr = (ctypes.c_void_p * np_k)(*[p.data_ptr() for p in params])
+        keep.append(arr)
+        d_s[r], d_th[r], d_out[r] = s.data_ptr(), th.data_ptr(), out.data_ptr()
+        d_par[r] = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
+        d_st[r] = st.data_ptr() if want_status else None
+        streams[r] = torch.cuda.current_stream(s.device).cuda_stream
+        outs.append(out)
+        stats.append(st)
+    handles = (ctypes.c_void_p * n_ctx)(*[c.handle for c in ctxs])
+    capi.check(lib.rimphony_batch_compute_multi_device(handles, n_ctx, kind, n_local, d_s, d_th, d_par, coeff_mask, 0, d_out,
+                                                       d_st if want_status else None, None, streams, 1 if synchronize else 0),
+               "rimphony_batch_compute_multi_device")
+    return (outs, stats) if want_status else outs
+
+
+class RcclComm:
+    """An RCCL communicator made through the library's own dlopen'ed librccl (rimphony_rccl_*): what a host that is not
+    Python would use for the gather of the output table.  One per rank; rank 0 makes the 128-byte id."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        lib = capi.load()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.handle = ctypes.c_void_p()
+        capi.check(lib.rimphony_rccl_comm_create(ctx.handle, rank, world, unique_id, ctypes.byref(self.handle)),
+                   "rimphony_rccl_comm_create")
+
+    @staticmethod
+    def available():
+        return bool(capi.load().rimphony_rccl_available())
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        capi.check(capi.load().rimphony_rccl_unique_id(buf), "rimphony_rccl_unique_id")
+        return buf
+
+    def gather_table(self, shard, n_total, root=0, scratch=None):
+        """shard: this rank's [m, 8] float64 device tensor (rows rank, rank + world, ... of the table); returns the
+        [n_total, 8] table on the root, None elsewhere."""
+        import torch
+        table = torch.empty((n_total, 8), dtype=torch.float64, device=shard.device) if self.rank == root else None
+        capi.check(capi.load().rimphony_rccl_gather_table(
+            self.ctx.handle, self.handle, self.rank, self.world, root, n_total, ctypes.c_void_p(shard.data_ptr()),
+            ctypes.c_void_p(table.data_ptr()) if table is not None else None,
+            ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None,
+            ctypes.c_void_p(torch.cuda.current_stream(shard.device).cuda_stream)), "rimphony_rccl_gather_table")
+        return table
+
+    def close(self):
+        if self.handle:
+            capi.load().rimphony_rccl_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 _default_ctx = None

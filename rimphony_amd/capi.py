@@ -18,6 +18,8 @@ SYMBOLS = [
     "rimphony_ctx_shared_mode", "rimphony_last_error", "rimphony_batch_compute_device_ex", "rimphony_batch_compute_ex",
     "rimphony_batch_compute_multi", "rimphony_status_histogram_device",
     "rimphony_hey_element_batch_device", "rimphony_hey_outer_batch_device", "rimphony_last_tail", "rimphony_deriv_probe_batch_device",
+    "rimphony_ctx_device", "rimphony_batch_compute_multi_device", "rimphony_rccl_available", "rimphony_rccl_unique_id",
+    "rimphony_rccl_comm_create", "rimphony_rccl_comm_destroy", "rimphony_rccl_gather_table",
 ]
 
 
@@ -129,6 +131,26 @@ def load():
                                                     c_void_p, c_void_p, c_void_p]
     lib.rimphony_status_histogram_device.restype = c_int
     lib.rimphony_status_histogram_device.argtypes = [c_void_p, c_size_t, c_void_p, POINTER(c_uint64), c_void_p]
+    # (an older build loaded through RIMPHONY_HIP_LIB for an A/B run -- tools/ab_libs.py -- predates these entries)
+    if hasattr(lib, "rimphony_ctx_device"):
+        lib.rimphony_ctx_device.restype = c_int
+        lib.rimphony_ctx_device.argtypes = [c_void_p, POINTER(c_int)]
+        lib.rimphony_batch_compute_multi_device.restype = c_int
+        lib.rimphony_batch_compute_multi_device.argtypes = [POINTER(c_void_p), c_int, c_int, POINTER(c_size_t), POINTER(c_void_p),
+                                                            POINTER(c_void_p), POINTER(POINTER(c_void_p)), c_uint32, c_int,
+                                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                            POINTER(c_void_p), c_int]
+        lib.rimphony_rccl_available.restype = c_int
+        lib.rimphony_rccl_available.argtypes = []
+        lib.rimphony_rccl_unique_id.restype = c_int
+        lib.rimphony_rccl_unique_id.argtypes = [c_void_p]
+        lib.rimphony_rccl_comm_create.restype = c_int
+        lib.rimphony_rccl_comm_create.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]
+        lib.rimphony_rccl_comm_destroy.restype = c_int
+        lib.rimphony_rccl_comm_destroy.argtypes = [c_void_p]
+        lib.rimphony_rccl_gather_table.restype = c_int
+        lib.rimphony_rccl_gather_table.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_size_t, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p]
     _lib = lib
     return lib
 
@@ -138,5 +160,6 @@ def check(rc, what):
         lib = load()
         msg = lib.rimphony_strerror(rc).decode()
         # the thread's last HIP failure only describes this call when this call failed in HIP (RIMPHONY_EHIP = -2)
-        detail = lib.rimphony_last_error().decode() if rc == -2 else ""
+        # (RIMPHONY_ERCCL = -7 and a librccl that could not be loaded, -6, leave their text there too)
+        detail = lib.rimphony_last_error().decode() if rc in (-2, -6, -7) else ""
         raise RimphonyError("%s failed: %s (code %d)%s" % (what, msg, rc, " -- " + detail if detail else ""))

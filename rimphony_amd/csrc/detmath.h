@@ -606,10 +606,9 @@ RIM_FN double rim_pow43(double x)
  * ((x/2)^nu / Gamma(nu + 1), nu = +-sigma, +-(sigma - 1) with sigma < ~4) divide by a Gamma function per series; the
  * shift-up-and-Stirling evaluation it replaces there took ~170 operations, this ~50. */
 #define RIM_RGAMMA_NEAR(z) ((z) > -8.5 && (z) < 9.5)
-RIM_FN double rim_rgamma_near(double z)
+/* S(z0) of the Taylor series 1 / Gamma(z0) = z0 S(z0), |z0| <= 1/2 (S_0 .. S_19) */
+RIM_FN double rim_rgamma_s(double z0)
 {
-    const double m = __builtin_rint(z);
-    const double z0 = z - m;                       /* exact */
     double s = 7.782263439905071e-12;
     s = rim_fma_k(s, z0, 1.0434267116911005e-10);
     s = rim_fma_k(s, z0, -1.18127457048702e-09);
@@ -629,7 +628,13 @@ RIM_FN double rim_rgamma_near(double z)
     s = rim_fma_k(s, z0, -0.04200263503409524);
     s = rim_fma_k(s, z0, -0.6558780715202539);
     s = rim_fma_k(s, z0, 0.5772156649015329);
-    s = rim_fma_k(s, z0, 1.0);       /* S(z0), S_0 .. S_19 */
+    s = rim_fma_k(s, z0, 1.0);
+    return s;
+}
+/* 1 / Gamma(m + z0) from S = S(z0) by the recurrence, m an integer-valued double: m >= 1 gives S / ((z0 + 1) .. (z0 + m - 1)),
+ * m <= 0 gives z0 S (z0 - 1) .. (z0 + m) -- exactly 0 at the poles */
+RIM_FN double rim_rgamma_shift(double s, double z0, double m)
+{
     if (m >= 1.) {
         double p = 1.;
         for (double k = 1.; k < m; k += 1.) p = p * (z0 + k);
@@ -638,6 +643,27 @@ RIM_FN double rim_rgamma_near(double z)
     double p = z0;
     for (double k = -1.; k >= m; k -= 1.) p = p * (z0 + k);
     return s * p;
+}
+RIM_FN double rim_rgamma_near(double z)
+{
+    const double m = __builtin_rint(z);
+    const double z0 = z - m;                       /* exact */
+    return rim_rgamma_shift(rim_rgamma_s(z0), z0, m);
+}
+/* The four reciprocal Gamma values in front of the J series of a quasi-resonant Faraday sample on its J/Y branch
+ * (heyvaerts.rs:335-336, 359-363, 437-441: besselj / bessely of orders sigma and sigma - 1, and by the reflection formula
+ * of Y their negatives): out = { 1/Gamma(sigma + 1), 1/Gamma(sigma), 1/Gamma(2 - sigma), 1/Gamma(1 - sigma) } for
+ * -7 < sigma < 8.  Two Taylor sums -- the arguments sigma + 1, sigma share their fractional part z0, and 2 - sigma,
+ * 1 - sigma the part -z0 -- two recurrences, and Gamma(z + 1) = z Gamma(z) for the other member of each pair (where the
+ * four separate evaluations took four sums and four recurrences).  A few ulp (tests/test_detmath.py). */
+RIM_FN void rim_rgamma_quad(double sigma, double out[4])
+{
+    const double m = __builtin_rint(sigma);
+    const double z0 = sigma - m;                   /* exact */
+    out[0] = rim_rgamma_shift(rim_rgamma_s(z0), z0, m + 1.);
+    out[1] = out[0] * sigma;
+    out[2] = rim_rgamma_shift(rim_rgamma_s(-z0), -z0, 2. - m);
+    out[3] = out[2] * (1. - sigma);
 }
 
 /* ---- atan, acos (only the Meissel "second" expansion of the Bessel seam needs them) -------------- */

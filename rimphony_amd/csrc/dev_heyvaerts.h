@@ -146,7 +146,64 @@ RIM_DEV double bessel_ynu(double nu, double x)
 // literal transcription sums the same series twice; here every distinct series is summed once, in one loop
 // body: orders sigma, sigma - 1, their negatives, and -- only for the integer orders that bessel_ynu
 // perturbs -- the perturbed orders.  Each value is the one bessel_jnu / bessel_ynu return.
-RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, double *ys, double *jm1, double *ym1)
+//
+// Round 4: for a NON-INTEGER order sigma in (0, 8) -- every sample of the path but the measure-zero integer ones, which
+// keep the evaluation above (bessel_jy_generic) -- the four series J_sigma, J_(sigma-1), J_(-sigma), J_(1-sigma) are
+// evaluated together (bessel_jy_fast), sharing what the four separate evaluations repeated:
+//   * ONE power h^sigma (h = x/2; one exponential of the double-double logarithm) and two reciprocals give
+//     h^(sigma-1) = h^sigma / h, h^(-sigma) = 1 / h^sigma, h^(1-sigma) = h / h^sigma (four exponentials before);
+//   * rim_rgamma_quad: the four 1 / Gamma from two Taylor sums and Gamma(z + 1) = z Gamma(z) (four sums before);
+//   * ONE sincos: sin(pi (sigma - 1)) = -sin(pi sigma), cos likewise, so Y_(sigma-1) = (cos(pi sigma) J_(sigma-1) +
+//     J_(1-sigma)) / sin(pi sigma);
+//   * the four ascending series in ONE loop that shares the powers (-q)^k, each as a numerator / denominator pair
+//     N_k = N_(k-1) d_k + (-q)^k, D_k = D_(k-1) d_k, d_k = k (k + nu), with one division at the end (a division per term
+//     before), until the term is below 1e-17 of the partial sum for all four.
+// The deterministic oracle evaluates the same expressions (oracle/rimo_heyvaerts.c jy_fast); the literal one keeps the
+// four separate pow / Gamma / term-recurrence evaluations.  special-fun's source is absent, so neither is "the
+// reference's arithmetic": both are pinned to scipy (tests/test_oracle_heyvaerts.py).
+RIM_DEV void bessel_jy_fast(double sigma, double x, bool want_ym1, double *js, double *ys, double *jm1, double *ym1)
+{
+    RIM_HIT(28);
+    const double h = 0.5 * x, q = h * h;
+    double ll;
+    const double lh = rim_log_dd(h, &ll);
+    const double p = rim_pow_from_log(lh, ll, sigma);          // h^sigma
+    const double hinv = 1. / h, pinv = 1. / p;
+    double rg[4];
+    rim_rgamma_quad(sigma, rg);                                 // 1 / Gamma of sigma + 1, sigma, 2 - sigma, 1 - sigma
+    double sn, cs;
+    rim_sincos(RIM_PI * sigma, &sn, &cs);
+    // orders: 0 sigma, 1 sigma - 1, 2 -sigma, 3 1 - sigma
+    const double nu0 = sigma, nu1 = sigma - 1., nu2 = -sigma, nu3 = 1. - sigma;
+    double n0 = 1., n1 = 1., n2 = 1., n3 = 1., d0 = 1., d1 = 1., d2 = 1., d3 = 1., pw = 1.;
+    const double mq = -q;
+    for (int k = 1; k <= 80; k++) {
+        RIM_HIT(30);
+        const double kd = (double) k;
+        pw = pw * mq;
+        const double e0 = kd * (kd + nu0), e1 = kd * (kd + nu1), e2 = kd * (kd + nu2), e3 = kd * (kd + nu3);
+        n0 = rim_fma(n0, e0, pw); d0 = d0 * e0;
+        n1 = rim_fma(n1, e1, pw); d1 = d1 * e1;
+        n2 = rim_fma(n2, e2, pw); d2 = d2 * e2;
+        n3 = rim_fma(n3, e3, pw); d3 = d3 * e3;
+        const double t = rim_fabs(pw);
+        if (t < 1e-17 * rim_fabs(n0) && t < 1e-17 * rim_fabs(n1) && t < 1e-17 * rim_fabs(n2) && t < 1e-17 * rim_fabs(n3)) break;
+    }
+    const double j_s = (p * rg[0]) * (n0 / d0);
+    const double j_sm1 = ((p * hinv) * rg[1]) * (n1 / d1);
+    const double j_ms = (pinv * rg[3]) * (n2 / d2);
+    *js = j_s;
+    *jm1 = j_sm1;
+    *ys = (cs * j_s - j_ms) / sn;
+    if (want_ym1) {
+        const double j_1ms = ((h * pinv) * rg[2]) * (n3 / d3);
+        *ym1 = (cs * j_sm1 + j_1ms) / sn;
+    } else {
+        *ym1 = 0.;
+    }
+}
+
+RIM_DEV void bessel_jy_generic(double sigma, double x, bool want_ym1, double *js, double *ys, double *jm1, double *ym1)
 {
     double nu_y[2], sn[2], cs[2];
     for (int w = 0; w < 2; w++) {
@@ -184,6 +241,13 @@ RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, do
     *ym1 = want_ym1 ? (cs[1] * j1 - r[3]) / sn[1] : 0.;
 }
 
+RIM_DEV void bessel_jy_set(double sigma, double x, bool want_ym1, double *js, double *ys, double *jm1, double *ym1)
+{
+    // (NaN takes the generic path and comes out as NaN there)
+    if (sigma > 0. && sigma < 8. && sigma != rim_floor(sigma)) bessel_jy_fast(sigma, x, want_ym1, js, ys, jm1, ym1);
+    else bessel_jy_generic(sigma, x, want_ym1, js, ys, jm1, ym1);
+}
+
 // Per-wave constants of the Faraday elements: the address of the series coefficient table.  On the device it is passed
 // through an empty volatile asm once, so that the compiler keeps it in a scalar register pair across the quadrature loops
 // instead of re-deriving the constant address (s_getpc + a GOT load and its wait) in front of every block of terms.
@@ -217,8 +281,18 @@ RIM_DEV void bessel_i_g4(const HeyConsts &hc, double x, double out[4])
 // Observer data of one Faraday coefficient (wave-uniform)
 struct HeyPoint {
     double s, cos_th, sin_th, sigma0, sigma0_sq;
+    double dinv;        // 1 / (sigma0 sin(theta)): gamma and the gamma-term of d f / d sigma MULTIPLY by it (round 4;
+                        // heyvaerts.rs:197, 478 divide by sigma0 sin(theta) per sample -- the literal oracle still does)
     int stokes;
 };
+
+// sigma0 and what follows from it, from s and the observer angle's sine
+RIM_DEV void hey_point_derive(HeyPoint &pt)
+{
+    pt.sigma0 = pt.s * pt.sin_th;
+    pt.sigma0_sq = pt.sigma0 * pt.sigma0;
+    pt.dinv = 1. / (pt.sigma0 * pt.sin_th);
+}
 
 struct HeyCoord { double sigma, pomega, x, gamma, mu; };
 
@@ -228,7 +302,7 @@ RIM_DEV HeyCoord fill_coord_vars(const HeyPoint &pt, double sigma, double pomega
     c.sigma = sigma;
     c.pomega = pomega;
     c.x = rim_sqrt(sigma * sigma - pomega * pomega - pt.sigma0_sq);
-    c.gamma = (sigma - pomega * pt.cos_th) / (pt.sigma0 * pt.sin_th);
+    c.gamma = (sigma - pomega * pt.cos_th) * pt.dinv;
     c.mu = (sigma * pt.cos_th - pomega) / (pt.sigma0 * pt.sin_th * rim_sqrt(c.gamma * c.gamma - 1.));
     return c;
 }
@@ -238,7 +312,7 @@ RIM_DEV double dfdsigma(const HeyPoint &pt, const DistParams &d, const HeyCoord 
 {
     double dfdg, dfdcxi;
     calc_f_derivatives<KIND>(d, c.gamma, c.mu, dfdg, dfdcxi);
-    const double g_term = dfdg / (pt.sigma0 * pt.sin_th);
+    const double g_term = dfdg * pt.dinv;
     double mu_term;
     if (dfdcxi == 0.) {
         mu_term = 0.;
@@ -262,6 +336,7 @@ struct HeyShared {
     double dfds;
     // quasi-resonant elements (heyvaerts.rs:302-373, 400-447)
     bool small_g;                   // g < G_APPROXIMATION_CUTOFF: the I_nu(g) forms
+    double smxox;                   // (sigma - x) / x
     double g, iv0, iv1, iv2, iv3;   // I_{2/3}, I_{-2/3}, I_{1/3}, I_{-1/3} of g
     double js, ys, jm1, ym1;        // J_sigma, Y_sigma, J_{sigma-1}, Y_{sigma-1} of x (ym1 only for "h")
     // non-resonant elements (heyvaerts.rs:379-394, 453-468)
@@ -289,14 +364,17 @@ RIM_DEV HeyShared hey_shared(const HeyPoint &pt, const DistParams &d, const HeyC
 {
     HeyShared sh;
     sh.small_g = true;
-    sh.g = 0.; sh.iv0 = 0.; sh.iv1 = 0.; sh.iv2 = 0.; sh.iv3 = 0.;
+    sh.smxox = 0.; sh.g = 0.; sh.iv0 = 0.; sh.iv1 = 0.; sh.iv2 = 0.; sh.iv3 = 0.;
     sh.js = 0.; sh.ys = 0.; sh.jm1 = 0.; sh.ym1 = 0.;
     sh.a1 = 0.; sh.a2 = 0.; sh.xa1p = 0.; sh.x_sq = 0.; sh.u = 0.; sh.u2 = 0.;
     if (qr) {
         RIM_HIT(26);
         sh.c = fill_coord_vars(pt, fixed, v);
         const HeyCoord &c = sh.c;
-        sh.g = RIM_SQRT_8_OVER_3 * rim_pow15(c.sigma - c.x) / rim_sqrt(c.x);
+        // g = sqrt(8)/3 (sigma - x)^1.5 / sqrt(x) (heyvaerts.rs:309, 406) as sqrt(8)/3 (sigma - x) sqrt((sigma - x) / x): one
+        // square root and the quotient the "h" element needs anyway, where the literal form takes two roots and a division
+        sh.smxox = (c.sigma - c.x) / c.x;
+        sh.g = RIM_SQRT_8_OVER_3 * (c.sigma - c.x) * rim_sqrt(sh.smxox);
         RIM_PROF_COUNT(22, 1);
 #if defined(RIM_PROF) && defined(__HIP_DEVICE_COMPILE__)
         { const unsigned long long big = __ballot(!(sh.g < RIM_G_APPROXIMATION_CUTOFF)); RIM_PROF_COUNT(23, big != 0 ? 1 : 0);
@@ -326,7 +404,7 @@ RIM_DEV double hey_member(const HeyPoint &pt, int stokes, bool qr, const HeyShar
     if (qr) {
         if (stokes == STOKES_Q) {
             const double po_sq = c.pomega * c.pomega;
-            const double smxox = (c.sigma - c.x) / c.x;
+            const double smxox = sh.smxox;
             double y1, y2;
             if (sh.small_g) {
                 const double plus = sh.iv0, minus = sh.iv1, plus1 = sh.iv2, minus1 = sh.iv3;

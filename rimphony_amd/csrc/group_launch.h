@@ -46,7 +46,7 @@ struct GroupArgs {
     unsigned gslots[2];             // members of group 0 and 1, 4 bits per member (output slots 0..5)
     int gnmem[2];
     GroupSlot *gboard;              // [gridDim.x]
-    double *gspill;                 // [gridDim.x][SPILL_GROUP_DOUBLES_PER_WAVE]
+    double *gspill;                 // [gridDim.x][P::SPILL_PER_WAVE]
     int coop;                       // cooperative tail on
     unsigned long long *prof;       // -DRIM_PROF builds: [gridDim.x][32] region timers / hit counters (else null)
 };

@@ -175,7 +175,7 @@ __device__ __forceinline__ void heyvaerts_group(const HeyPoint &pt0, const DistP
             const int m = __builtin_ctz(rem);
             HeyPoint pt = pt0;
             pt.stokes = hey_slot_stokes(group_slot(slots, m));
-            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_HEYGOUTER, m);
             HeyTask T = park[m];
             hey_uniformize(T);
             SymBatch B;
@@ -240,7 +240,7 @@ __device__ __forceinline__ void heyvaerts_group(const HeyPoint &pt0, const DistP
             const int m = __builtin_ctz(rem);
             HeyPoint pt = pt0;
             pt.stokes = hey_slot_stokes(group_slot(slots, m));
-            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_HEYGOUTER, m);
             HeyTask T = park[m];
             hey_uniformize(T);
             SymBatch B;

@@ -356,8 +356,7 @@ static __device__ HeyPoint hey_point_of(const PointArgs &pa)
     HeyPoint pt;
     pt.s = pa.s;
     rim_sincos(pa.theta, &pt.sin_th, &pt.cos_th);
-    pt.sigma0 = pt.s * pt.sin_th;
-    pt.sigma0_sq = pt.sigma0 * pt.sigma0;
+    hey_point_derive(pt);
     pt.stokes = pa.stokes;
     return pt;
 }
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(64) void hey_outer_kernel(PointArgs pa, const doubl
     __syncthreads();
     HeyPoint pt = hey_point_of(pa);
     pt.s = uni(pt.s); pt.sin_th = uni(pt.sin_th); pt.cos_th = uni(pt.cos_th);
-    pt.sigma0 = uni(pt.sigma0); pt.sigma0_sq = uni(pt.sigma0_sq);
+    pt.sigma0 = uni(pt.sigma0); pt.sigma0_sq = uni(pt.sigma0_sq); pt.dinv = uni(pt.dinv);
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = pa.par[k];
     dist_prepare<KIND>(d, norm_ptr[0]);

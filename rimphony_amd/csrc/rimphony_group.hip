@@ -30,7 +30,8 @@ struct SymGroupProblem {
     typedef TaskState Task;
     typedef GroupPark Park;
     struct Ctx { SymPoint pt; DistParams d; };
-    enum : int { QUEUE = 0, TAIL_WORD = 14, STATS_WORD = 8, WAVES = RIM_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1 };
+    enum : int { QUEUE = 0, TAIL_WORD = 14, STATS_WORD = 8, WAVES = RIM_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1,
+                 GSPILL_OUTER = SPILL_GOUTER, SPILL_PER_WAVE = SPILL_GROUP_DOUBLES_PER_WAVE };
     static __device__ __forceinline__ void init(const SymArgs &, Ctx &c, double *)
     { c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.coeff = 0; c.pt.stokes = 0; }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned slots, Ctx &c, double &norm)
@@ -59,11 +60,12 @@ struct HeyGroupProblem {
     typedef HeyTask Task;
     typedef GroupParkBase Park;
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
-    enum : int { QUEUE = 4, TAIL_WORD = 15, STATS_WORD = 10, WAVES = RIM_HEY_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1 };
+    enum : int { QUEUE = 4, TAIL_WORD = 15, STATS_WORD = 10, WAVES = RIM_HEY_GROUP_WAVES, EXTRA_LDS_DOUBLES = 1,
+                 GSPILL_OUTER = SPILL_HEYGOUTER, SPILL_PER_WAVE = SPILL_HEYGROUP_DOUBLES_PER_WAVE };
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
         c.hc = hey_consts();
-        c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.stokes = STOKES_Q;
+        c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.dinv = 0.; c.pt.stokes = STOKES_Q;
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned, Ctx &c, double &norm)
     {
@@ -72,8 +74,8 @@ struct HeyGroupProblem {
         rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
         pt.sin_th = uni(pt.sin_th);
         pt.cos_th = uni(pt.cos_th);
-        pt.sigma0 = uni(pt.s * pt.sin_th);
-        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
+        hey_point_derive(pt);
+        pt.sigma0 = uni(pt.sigma0); pt.sigma0_sq = uni(pt.sigma0_sq); pt.dinv = uni(pt.dinv);
         pt.stokes = STOKES_Q;
         load_params<KIND>(a.pp, i, c.d);
         norm = uni(a.norm[i]);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
     __shared__ double s_extra[P::EXTRA_LDS_DOUBLES];
     const GKLane g = gk_lane_init(s_tab);
     const int lane = g.lane;
-    double *const inner_spill = ga.gspill + (size_t) blockIdx.x * SPILL_GROUP_DOUBLES_PER_WAVE;
+    double *const inner_spill = ga.gspill + (size_t) blockIdx.x * P::SPILL_PER_WAVE;
     double *const outer_spill = inner_spill + RIM_GROUP * RIM_ISTORE_DOUBLES(SPILL_GINNER);
     if (threadIdx.x == 0) {
         s_gp.ctr = WaveCounters{0, 0, 0};
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                         if (a.status) a.status[own_i * 8 + sl] = st;
 #endif
                         // the heaviest member of the launch: its sequential chain of batches bounds the launch's tail
-                        atomicMax(a.queue + P::TAIL_WORD, ((unsigned long long) P::batches(T) << 24) | ((unsigned long long) own_i & 0xffffffull));
+                        atomicMax(a.queue + P::TAIL_WORD, ((unsigned long long) P::batches(T) << 40) | ((unsigned long long) own_i & 0xffffffffffull));
                     }
                 }
                 __syncthreads();
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
             const unsigned turn = P::turn(s_park, alive);
             for (unsigned rem = turn; rem; rem &= rem - 1) {
                 const int m = __builtin_ctz(rem);
-                const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+                const IStore outer = group_store(nullptr, 0, outer_spill, P::GSPILL_OUTER, m);
                 typename P::Task T = s_park[m];
                 P::uniformize(T);
                 SymBatch B;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
         RIM_PROF_T(t_cons);
         for (unsigned rem = posted; rem; rem &= rem - 1) {
             const int m = __builtin_ctz(rem);
-            const IStore outer = group_store(nullptr, 0, outer_spill, SPILL_GOUTER, m);
+            const IStore outer = group_store(nullptr, 0, outer_spill, P::GSPILL_OUTER, m);
             typename P::Task T = s_park[m];
             P::uniformize(T);
             SymBatch B;
@@ -645,5 +647,8 @@ int rim_group_launch(int kind, int faraday, unsigned grid, hipStream_t st, const
         default: launch<SymGroupProblem<3>>(grid, st, ga); break;
         }
     }
-    return hipGetLastError() == hipSuccess ? RIMPHONY_OK : RIMPHONY_EHIP;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return RIMPHONY_OK;
+    rim_set_last_error("group_kernel launch", hipGetErrorString(e));
+    return RIMPHONY_EHIP;
 }

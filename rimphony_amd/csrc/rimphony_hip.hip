@@ -162,8 +162,8 @@ struct HeyvaertsProblem {
         rim_sincos(a.theta[i], &pt.sin_th, &pt.cos_th);
         pt.sin_th = uni(pt.sin_th);
         pt.cos_th = uni(pt.cos_th);
-        pt.sigma0 = uni(pt.s * pt.sin_th);
-        pt.sigma0_sq = uni(pt.sigma0 * pt.sigma0);
+        hey_point_derive(pt);
+        pt.sigma0 = uni(pt.sigma0); pt.sigma0_sq = uni(pt.sigma0_sq); pt.dinv = uni(pt.dinv);
         pt.stokes = uni(c_slot_stokes[slot]);
         load_params<KIND>(a.pp, i, c.d);
         norm = uni(a.norm[i]);
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     int st = 0;
                     const double val = P::result(cx, T, st);
                     // the heaviest task of the launch: its sequential chain of batches bounds the launch's tail
-                    // (queue word 15 of the kernel's block: (batches << 24) | point index; rimphony_last_tail)
-                    if (lane == 0) atomicMax(a.queue + (P::QUEUE ? 15 : 14), ((unsigned long long) T.batches << 24) | ((unsigned long long) own_i & 0xffffffull));
+                    // (queue word 15 of the kernel's block: (batches << 40) | point index; rimphony_last_tail)
+                    if (lane == 0) atomicMax(a.queue + (P::QUEUE ? 15 : 14), ((unsigned long long) T.batches << 40) | ((unsigned long long) own_i & 0xffffffffffull));
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
 #if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: the task's number of batches in the upper half of the status word)
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         atomicAdd(a.queue + 12, n_polls_total);
         atomicAdd(a.queue + 13, n_empty_claims);
         atomicAdd(a.queue + 14, eval_ticks);
-        (void) max_wait;          // [15] is the heaviest task: (batches << 24) | point index
+        (void) max_wait;          // [15] is the heaviest task: (batches << 40) | point index
 #endif
     }
 }
@@ -815,9 +815,11 @@ struct rimphony_ctx {
     // group kernel (rimphony_group.hip): per-wave spill regions and board, resident workgroups per CU by kind
     double *d_gspill;
     size_t gspill_waves;
+    int gspill_faraday;             // the region is sized for the Faraday pair's longer outer lists
     GroupSlot *d_gboard;            // [gboard_slots] + flag words behind
     size_t gboard_slots;
     int resident_group[2][4];       // [Symphony groups / Faraday pair][kind]
+    int f32_variant;                // RIMPHONY_F32_VARIANT=1: accept RIMPHONY_PRECISION_F32_INTEGRAND (measurement hook)
     int sym_solo;                   // RIMPHONY_SYM_SOLO=1: one wave per (point, coefficient), the round-2 kernel (A/B measurements)
     int faraday_group;              // RIMPHONY_FARADAY_GROUP=1: rho_Q and rho_V of a point in lock-step (measured slower: DESIGN.md section 5)
 };
@@ -852,6 +854,7 @@ extern "C" const char *rimphony_strerror(int code)
     case RIMPHONY_ENODEVICE: return "no usable HIP device (this library has no CPU fallback)";
     case RIMPHONY_EBUSY: return "the device is in use by another rimphony context (RIMPHONY_EXCLUSIVE=1)";
     case RIMPHONY_ENOTSUP: return "not supported";
+    case RIMPHONY_ERCCL: return "RCCL call failed";
     default: return "unknown error";
     }
 }
@@ -927,6 +930,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     if (!c->mu) { delete c; return RIMPHONY_ENOMEM; }
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
+    { const char *e = getenv("RIMPHONY_F32_VARIANT"); c->f32_variant = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_FARADAY_GROUP"); c->faraday_group = (e && e[0] == '1'); }
     c->shared_mode = take_device_lock(device, &c->lock_fd);
     if (c->shared_mode) {
@@ -969,6 +973,12 @@ extern "C" void rimphony_ctx_destroy(rimphony_ctx *c)
 }
 
 extern "C" int rimphony_ctx_shared_mode(const rimphony_ctx *c) { return c ? c->shared_mode : RIMPHONY_EINVAL; }
+extern "C" int rimphony_ctx_device(const rimphony_ctx *c, int *device)
+{
+    if (!c || !device) return RIMPHONY_EINVAL;
+    *device = c->device;
+    return RIMPHONY_OK;
+}
 
 int rim_ctx_enter(rimphony_ctx *c, hipStream_t st)
 {
@@ -1183,12 +1193,24 @@ static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t co
     }
     if (c->shared_mode) resident_per_cu = resident_per_cu >= 8 ? resident_per_cu / 4 : 2;
     const unsigned grid = persistent_grid(c, want_waves, resident_per_cu);
-    if (c->gspill_waves < grid) {
+    if (c->gspill_waves < grid || (faraday && !c->gspill_faraday)) {
         if (c->d_gspill) (void) hipFree(c->d_gspill);
         c->d_gspill = nullptr;
         c->gspill_waves = 0;
-        if (hipMalloc(&c->d_gspill, (size_t) grid * SPILL_GROUP_DOUBLES_PER_WAVE * sizeof(double)) != hipSuccess) return RIMPHONY_ENOMEM;
+        // per wave: four members' lists at the GSL limits of the path -- 0.86 MB for the Symphony groups (5000 + 1000
+        // entries), 1.3 MB for the Faraday pair in lock-step (4096 + 4096; off by default): 4.4 GB of the 288 for a full
+        // persistent grid of 5120 waves, held until the context is destroyed
+        const size_t per_wave = faraday ? SPILL_HEYGROUP_DOUBLES_PER_WAVE : SPILL_GROUP_DOUBLES_PER_WAVE;
+        const size_t bytes = (size_t) grid * (per_wave > SPILL_GROUP_DOUBLES_PER_WAVE ? per_wave : SPILL_GROUP_DOUBLES_PER_WAVE) * sizeof(double);
+        if (hipMalloc(&c->d_gspill, bytes) != hipSuccess) {
+            (void) hipGetLastError();
+            char msg[160];
+            snprintf(msg, sizeof msg, "%zu MB for the subinterval spill region of %u waves (lists beyond the LDS part)", bytes >> 20, grid);
+            rim_set_last_error("hipMalloc", msg);
+            return RIMPHONY_ENOMEM;
+        }
         c->gspill_waves = grid;
+        c->gspill_faraday = faraday;
     }
     if (c->gboard_slots < grid) {
         if (c->d_gboard) (void) hipFree(c->d_gboard);
@@ -1214,10 +1236,26 @@ static int launch_group(rimphony_ctx *c, int kind, const SymArgs &a, uint32_t co
     HIP_TRY(hipMemset2DAsync(c->d_gboard, sizeof(GroupSlot), 0, 32, grid, st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, ga.base.board_flags, grid);
     HIP_TRY(hipEventRecord(faraday ? c->ev_fstart : c->ev_start, st));
-    const int rc = rim_group_launch(kind, faraday, grid, st, ga);
-    if (rc) { rim_set_last_error("group_kernel launch", hipGetErrorString(hipGetLastError())); return rc; }
+    const int rc = rim_group_launch(kind, faraday, grid, st, ga);       // sets the thread's last error itself
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(faraday ? c->ev_fstop : c->ev_stop, st));
     if (faraday) c->evf_valid = 1; else c->ev_valid = 1;
+    return RIMPHONY_OK;
+}
+
+// `precision` of the batch entries.  F64 is the product.  F32_INTEGRAND (BASELINE configs[4]'s fp32-core integrand) is
+// NOT offered: on the anisotropic distributions -- pitchy kappa is the one configs[4] names -- its 1e-7 non-smooth noise
+// sits above GSL's round-off detectors on integrals that cancel (1.53 x slower than fp64, 1.9 % new NaNs, round 2); on the
+// power-law and thermal distributions it ran 0.90 / 0.96 of the fp64 time of the ROUND-2 kernel it is built on, and the
+// fp64 default has since moved to the group kernel at 0.66 of that time: the variant is 1.36-1.43 x SLOWER than fp64 and
+// lossier.  A precision that is slower and lossier is not a mode, it is a trap: RIMPHONY_ENOTSUP for
+// every kind, unless the context was created with RIMPHONY_F32_VARIANT=1 (measurement hook: tools/f32_variant.py, the
+// error-envelope test), and even then not for the anisotropic kinds.
+static int rim_precision_check(const rimphony_ctx *c, int kind, int precision)
+{
+    if (precision == RIMPHONY_PRECISION_F64) return RIMPHONY_OK;
+    if (precision != RIMPHONY_PRECISION_F32_INTEGRAND || !c || !c->f32_variant) return RIMPHONY_ENOTSUP;
+    if (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA) return RIMPHONY_ENOTSUP;
     return RIMPHONY_OK;
 }
 
@@ -1234,13 +1272,7 @@ extern "C" int rimphony_batch_compute_device_ex(rimphony_ctx *c, int kind, size_
                                                 double *d_out, int32_t *d_status, uint64_t *d_work, void *stream)
 {
     if (!c || kind < 0 || kind > 3) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
-    // The fp32-integrand variant is not offered for the anisotropic distributions: measured on pitchy kappa -- the
-    // distribution BASELINE configs[4] names -- its 1e-7 non-smooth noise sits above GSL's round-off detectors on integrals
-    // that cancel, the quadratures bisect 32 % more and give up: 1.53 x SLOWER than fp64 with 1.9 % new NaNs
-    // (profiles/r2_f32_integrand_variant.txt).  A precision that is slower and lossier is not a mode, it is a trap.
-    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
-        return RIMPHONY_ENOTSUP;
+    { const int prc = rim_precision_check(c, kind, precision); if (prc) return prc; }
     if (n == 0) return RIMPHONY_OK;          // empty batch: nothing to read or write
     if (!d_out || !d_s || !d_theta) return RIMPHONY_EINVAL;
     hipStream_t st = (hipStream_t) stream;
@@ -1376,6 +1408,12 @@ extern "C" int rimphony_debug_heartbeat(rimphony_ctx *c, uint64_t task, uint64_t
         c->hb_host = (unsigned long long *) h;
         c->hb_dev = (unsigned long long *) d;
     }
+    // the group kernel (the default for the Symphony slots) writes no heartbeat: a watchdog polling word [10] would
+    // wait for ever
+    if (!(task & (1ull << 62)) && !c->sym_solo) {
+        rim_set_last_error("rimphony_debug_heartbeat", "Symphony tasks are only watched with RIMPHONY_SYM_SOLO=1");
+        return RIMPHONY_ENOTSUP;
+    }
     c->hb_task = task;
     *host_words = (uint64_t *) c->hb_host;
     return RIMPHONY_OK;
@@ -1441,12 +1479,15 @@ extern "C" int rimphony_last_work(rimphony_ctx *c, rimphony_work *out)
 extern "C" int rimphony_last_tail(rimphony_ctx *c, uint64_t out[8])
 {
     if (!c || !out) return RIMPHONY_EINVAL;
+    // the queue words belong to the context's workspace: read them under its lock, after the last call's kernels
+    // (a concurrent call on the same context resets them)
+    std::lock_guard<std::recursive_mutex> lock(*c->mu);
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[16];
     if (c->ev_batch_valid) HIP_TRY(hipEventSynchronize(c->ev_batch));
     HIP_TRY(hipMemcpy(h, c->d_queue, sizeof h, hipMemcpyDeviceToHost));
-    out[0] = h[14] >> 24; out[1] = h[14] & 0xffffffull;
-    out[2] = h[15] >> 24; out[3] = h[15] & 0xffffffull;
+    out[0] = h[14] >> 40; out[1] = h[14] & 0xffffffffffull;        // (batches << 40) | row: rows to 1.1e12
+    out[2] = h[15] >> 40; out[3] = h[15] & 0xffffffffffull;
     out[4] = h[8]; out[5] = h[9];
     out[6] = h[10]; out[7] = h[11];
     return RIMPHONY_OK;
@@ -1457,9 +1498,7 @@ extern "C" int rimphony_batch_compute_ex(rimphony_ctx *c, int kind, size_t n,
                                          uint32_t coeff_mask, int precision, double *out, int32_t *status, uint64_t *work)
 {
     if (!c || !out || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
-    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
-        return RIMPHONY_ENOTSUP;
+    { const int prc = rim_precision_check(c, kind, precision); if (prc) return prc; }
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];
@@ -1535,9 +1574,7 @@ extern "C" int rimphony_batch_compute_multi(rimphony_ctx *const *ctxs, int n_ctx
 {
     if (!ctxs || n_ctx < 1 || n_ctx > 64 || kind < 0 || kind > 3 || !params) return RIMPHONY_EINVAL;
     for (int r = 0; r < n_ctx; r++) if (!ctxs[r]) return RIMPHONY_EINVAL;
-    if (precision != RIMPHONY_PRECISION_F64 && precision != RIMPHONY_PRECISION_F32_INTEGRAND) return RIMPHONY_ENOTSUP;
-    if (precision == RIMPHONY_PRECISION_F32_INTEGRAND && (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA))
-        return RIMPHONY_ENOTSUP;
+    { const int prc = rim_precision_check(ctxs[0], kind, precision); if (prc) return prc; }
     if (n == 0) return RIMPHONY_OK;
     if (!s || !theta || !out) return RIMPHONY_EINVAL;
     const int np = NPARAMS[kind];

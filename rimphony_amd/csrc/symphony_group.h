@@ -43,8 +43,10 @@ namespace rim {
 // per-member global spill behind the LDS lists: the GSL limits of the path (symphony.rs:375-380: 5000; :264-269: 1000)
 // (the Faraday group -- heyvaerts_group.h -- uses the same stores: its limits are 4096 / 4096, heyvaerts.rs:82-83)
 #define SPILL_GINNER 5000
-#define SPILL_GOUTER 4096
+#define SPILL_GOUTER 1000               // symphony.rs:264-269: the n-chunk quadrature's limit
+#define SPILL_HEYGOUTER 4096            // heyvaerts.rs:82-83 (the Faraday pair in lock-step, heyvaerts_group.h)
 #define SPILL_GROUP_DOUBLES_PER_WAVE (RIM_GROUP * (RIM_ISTORE_DOUBLES(SPILL_GINNER) + RIM_ISTORE_DOUBLES(SPILL_GOUTER)))
+#define SPILL_HEYGROUP_DOUBLES_PER_WAVE (RIM_GROUP * (RIM_ISTORE_DOUBLES(SPILL_GINNER) + RIM_ISTORE_DOUBLES(SPILL_HEYGOUTER)))
 
 // A member is identified by its output slot 0..5 (lib.rs:176-177): coefficient = slot & 1 (emission, absorption),
 // Stokes parameter = slot >> 1.  `slots` packs the members' slots, 4 bits each.

@@ -28,7 +28,7 @@ double devh_hey_element(int kind, int stokes, double s, double cos_th, double si
                         int qr, double fixed, double v)
 {
     HeyPoint pt;
-    pt.s = s; pt.cos_th = cos_th; pt.sin_th = sin_th; pt.sigma0 = s * sin_th; pt.sigma0_sq = pt.sigma0 * pt.sigma0;
+    pt.s = s; pt.cos_th = cos_th; pt.sin_th = sin_th; hey_point_derive(pt);
     pt.stokes = stokes;
     DistParams d;
     for (int i = 0; i < 5; i++) d.par[i] = par[i];

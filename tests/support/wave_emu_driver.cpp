@@ -52,7 +52,7 @@ static void lane_body(EmuTask *t)
         __shared__ HeyTask s_hpark;
         HeyPoint hp;
         hp.s = pt.s; hp.sin_th = pt.sin_th; hp.cos_th = pt.cos_th;
-        hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = t->stokes;
+        hey_point_derive(hp); hp.stokes = t->stokes;
         const HeyConsts hc = hey_consts();
         val = heyvaerts_coefficient<KIND>(hp, d, hc, g, inner, outer, &s_hpark, &s_qpark, st);
     } else {
@@ -241,14 +241,14 @@ static void hey_group_lane_body(EmuGroupTask *t)
     __shared__ double s_ginner[RIM_GROUP * RIM_ISTORE_DOUBLES(CAP_GINNER)];
     __shared__ HeyTask s_park[RIM_GROUP];
     __shared__ GroupParkBase s_gp;
-    static double s_spill[SPILL_GROUP_DOUBLES_PER_WAVE];
+    static double s_spill[SPILL_HEYGROUP_DOUBLES_PER_WAVE];
     const GKLane g = gk_lane_init(s_tab);
     if (g.lane == 0) { s_gp.ctr = WaveCounters{0, 0, 0}; s_gp.member_passes = 0; s_gp.stash_filed = 0; s_gp.stash_used = 0; s_gp.hb = nullptr; }
     wv_sync();
     HeyPoint hp;
     hp.s = uni(t->s);
     rim_sincos(t->theta, &hp.sin_th, &hp.cos_th);
-    hp.sigma0 = hp.s * hp.sin_th; hp.sigma0_sq = hp.sigma0 * hp.sigma0; hp.stokes = STOKES_Q;
+    hey_point_derive(hp); hp.stokes = STOKES_Q;
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = t->par[k];
     dist_prepare<KIND>(d, t->norm);

@@ -88,6 +88,37 @@ def test_fixed_order_bessel_i_against_mpmath(oracle, oracle_libm):
             assert np.abs(err).max() < 9.0 and err.std() < 2.0 and abs(err.mean()) < 1.5, (nu, np.abs(err).max(), err.std(), err.mean())
 
 
+def test_joint_jy_evaluation_against_mpmath(oracle, oracle_libm):
+    """J_sigma, Y_sigma, J_(sigma-1), Y_(sigma-1) of the J/Y branch (g >= 10: sigma < ~3.05, x <~ 0.3; checked with margin
+    to sigma 3.6, x 1.2) against mpmath, both flavours.  The deterministic flavour (= the kernels) evaluates the four series
+    jointly (dev_heyvaerts.h bessel_jy_fast: one power, rim_rgamma_quad, numerator / denominator recurrences); the
+    literal one by four separate pow / Gamma / term recurrences.  J to 2e-14; Y carries the cancellation of the reflection
+    formula near half-integer orders (as Cephes' yv does), so it is held to 1e-9 of max(|Y|, |J_-nu| / |sin|) (worst case, both flavours alike:
+    1.5e-10 at sigma = 1.0000001)."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    rng = np.random.default_rng(9)
+    sig = np.concatenate([rng.uniform(0.05, 3.6, 400), [0.5, 1.5, 2.5, 0.3333333333333333, 2.9999999, 1.0000001]])
+    xs = np.exp(rng.uniform(math.log(1e-5), math.log(1.2), len(sig)))
+    out = (ctypes.c_double * 4)()
+    for L in (oracle, oracle_libm):
+        L.rimo_bessel_jy_set.restype = None
+        L.rimo_bessel_jy_set.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double * 4]
+        worst_j = worst_y = 0.
+        for s_, x_ in zip(sig, xs):
+            L.rimo_bessel_jy_set(float(s_), float(x_), out)
+            for k, nu in ((0, s_), (2, s_ - 1.)):
+                ej = mp.besselj(mp.mpf(float(nu)), mp.mpf(float(x_)))
+                ey = mp.bessely(mp.mpf(float(nu)), mp.mpf(float(x_)))
+                worst_j = max(worst_j, float(abs(mp.mpf(out[k]) - ej) / abs(ej)))
+                scale = max(abs(ey), abs(mp.besselj(-mp.mpf(float(nu)), mp.mpf(float(x_))) / mp.sin(mp.pi * mp.mpf(float(nu)))))
+                worst_y = max(worst_y, float(abs(mp.mpf(out[k + 1]) - ey) / scale))
+        assert worst_j < 2e-14 and worst_y < 1e-9, (worst_j, worst_y)
+    # integer orders keep the generic evaluation (the documented 2^-26 step off the pole of the reflection formula)
+    oracle.rimo_bessel_jy_set(2.0, 0.1, out)
+    assert abs(out[1] / sp.yv(2.0, 0.1) - 1) < 1e-6 and abs(out[0] / sp.jv(2.0, 0.1) - 1) < 1e-14
+
+
 def test_faraday_via_dispatch(oracle):
     d, _ = oracle_bind.mkdist(oracle, 0, [2.5, 10., 1e12, 1e10])
     out = np.zeros(8)

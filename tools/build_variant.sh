@@ -4,4 +4,4 @@
 out="$1"; shift
 cd "$(dirname "$0")/.." && mkdir -p "$(dirname "$out")" && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off \
   -mllvm -disable-machine-licm -Xarch_host -mfma "$@" -Iinclude -Irimphony_amd/csrc \
-  rimphony_amd/csrc/rimphony_hip.hip rimphony_amd/csrc/rimphony_diag.hip rimphony_amd/csrc/rimphony_group.hip -o "$out"
+  rimphony_amd/csrc/rimphony_hip.hip rimphony_amd/csrc/rimphony_diag.hip rimphony_amd/csrc/rimphony_group.hip rimphony_amd/csrc/rimphony_multi.hip -ldl -o "$out"

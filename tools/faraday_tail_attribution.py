@@ -25,8 +25,8 @@ from rimphony_amd import workload
 
 BITS = [("third_powers", 1 << 0), ("rgamma_near", 1 << 1), ("series_pairs", 1 << 2), ("nr_upowers", 1 << 3),
         ("pow15_limits", 1 << 4), ("own_exp_log_pow", 1 << 5), ("powexp_one_exp", 1 << 6), ("gk_tree_order", 1 << 7),
-        ("rescale_xsqrtx", 1 << 8), ("own_sincos", 1 << 9)]
-ALL = (1 << 12) - 1
+        ("rescale_xsqrtx", 1 << 8), ("own_sincos", 1 << 9), ("dinv_products", 1 << 12), ("g_one_root", 1 << 13), ("jy_joint", 1 << 14)]
+ALL = (1 << 15) - 1
 FARADAY_ALL = sum(b for _, b in BITS)
 TABLES = [("cfg2_powerlaw_8", 1000000), ("cfg3_thermal_8", 0), ("cfg4_pitchypl_8", 0), ("cfg5_pitchykappa_8", 0)]
 
