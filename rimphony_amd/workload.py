@@ -55,9 +55,16 @@ CONFIGS = {
 
 def make_batch(config, n, start=0):
     """Return (kind, mask, s, theta, [params...]) for points start .. start+n-1 of a config."""
+    return make_rows(config, np.arange(start, start + n, dtype=np.uint64))
+
+
+def make_rows(config, rows):
+    """The same for an arbitrary set of row indices of a config's table (the generator is counter-based: row i is a
+    function of i alone) -- e.g. one rank's interleaved share rank, rank + world, ... of a table."""
     kind, off, mask = CONFIGS[config]
     seed = SEED_BASE + off
-    idx = np.arange(start, start + n, dtype=np.uint64)
+    idx = np.asarray(rows, dtype=np.uint64)
+    n = len(idx)
     s = _log(uniform01(seed, idx, 0), 0.1, 1e4)
     theta = _lin(uniform01(seed, idx, 1), 0.05, 1.52)
     if config.endswith("_corner"):

@@ -419,8 +419,10 @@ def test_full_size_table_properties(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("cfg", ["cfg2_powerlaw_8", "cfg3_thermal_8", "cfg4_pitchypl_8", "cfg5_pitchykappa_8"])
 def test_all_eight_table_properties(gpu_ctx, cfg):
-    """The same properties for the eight-coefficient configurations on 16384 rows each (their full sizes, 1e7-1e8
-    rows, are hours of GPU time): NaN <=> the NONFINITE status bit in every slot, j_I and alpha_I positive where
+    """The same properties for the eight-coefficient configurations on 16384 rows each.  (Their full sizes are minutes, not
+    hours, of one GPU -- configs[2]'s 1e7 thermal rows about 5 minutes, a GPU's 1.25e6-row share of configs[3] about 2 --
+    which is still too long for a test: the full-size runs are tools/full_size_run.py, profiles/r4_full_size_*.txt, with
+    the same properties checked tile by tile.)  NaN <=> the NONFINITE status bit in every slot, j_I and alpha_I positive where
     finite for the isotropic distributions, and
     2048 scattered rows recomputed alone give the same bits in all eight slots."""
     n = 16384
