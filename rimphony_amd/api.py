@@ -442,7 +442,7 @@ def compute_batch_multi_device(ctxs, kind, shards, coeff_mask=SLOTS_ALL, want_st
 
 
 class RcclComm:
-    """An RCCL communicator made through the library's own dlopen'ed librccl (rimphony_rccl_*): what a host that is not
+    """An RCCL communicator made through the library's own own run-time-loaded librccl (rimphony_rccl_*): what a host that is not
     Python would use for the gather of the output table.  One per rank; rank 0 makes the 128-byte id."""
 
     def __init__(self, ctx, rank, world, unique_id):

@@ -202,6 +202,17 @@ def read(*parts, env_override=None):
     return open(path or os.path.join(*parts)).read()
 
 
+def literal_only(text):
+    """The oracle sources choose between the literal form of a quantity and the deterministic (lock-step) one with
+    RIMO_LIT(bit) (oracle/rimo_math.h: compile-time constants in the two shipped flavours, run-time switches in the
+    attribution build).  What is compared with the reference's text here is the LITERAL branch of each such choice."""
+    text = re.sub(r"if \(!RIMO_LIT\(\w+\)\) \{[^{}]*\}", "", text)                                   # a deterministic-only block
+    text = re.sub(r"if \(RIMO_LIT\(\w+\)\)\s*(return [^;]+;)\s*return [^;]+;", r"\1", text)          # if (lit) return A; return B;
+    text = re.sub(r"if \(RIMO_LIT\(\w+\)\)\s*([^;{}]+;)\s*else\s*[^;{}]+;", r"\1", text)           # if (lit) A; else B;
+    text = re.sub(r"RIMO_LIT\(\w+\) \? ([^;:\n]+) : [^;\n]+;", r"\1;", text)                              # lit ? A : B
+    return text
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not mounted at %s: nothing to check" % REF)
@@ -214,8 +225,8 @@ def main():
     dev_hey = read(ROOT, "rimphony_amd", "csrc", "dev_heyvaerts.h", env_override="RIMPHONY_CHECK_DEV_HEYVAERTS")
     wave_hey = read(ROOT, "rimphony_amd", "csrc", "heyvaerts_wave.h")
     ora_sym = read(ROOT, "oracle", "rimo_symphony.c")
-    ora_hey = read(ROOT, "oracle", "rimo_heyvaerts.c")
-    ora_dist = read(ROOT, "oracle", "rimo_dist.c", env_override="RIMPHONY_CHECK_ORACLE_DIST")
+    ora_hey = literal_only(read(ROOT, "oracle", "rimo_heyvaerts.c"))
+    ora_dist = literal_only(read(ROOT, "oracle", "rimo_dist.c", env_override="RIMPHONY_CHECK_ORACLE_DIST"))
 
     s, gamma, n, cos_th, sin_th = pos("s gamma n cos_th sin_th")
     Jn, Jp = sp.symbols("Jn Jp")
@@ -488,7 +499,9 @@ def main():
 
     # ================= Heyvaerts: coordinates, chain rule, inner limits, scaling =================
     sig, po, s0, s0sq = pos("sigma pomega sigma0 sigma0_sq")
-    henv = base_env({"sigma": sig, "pomega": po, "sigma0": s0, "sigma0_sq": s0sq, "cos_th": cos_th, "sin_th": sin_th,
+    # (round 4: the kernels multiply by dinv = 1 / (sigma0 sin_th), formed once per coefficient by hey_point_derive)
+    assert "pt.dinv = 1. / (pt.sigma0 * pt.sin_th);" in dev_hey
+    henv = base_env({"sigma": sig, "pomega": po, "sigma0": s0, "sigma0_sq": s0sq, "cos_th": cos_th, "sin_th": sin_th, "dinv": 1 / (s0 * sin_th),
                      "cos_observer_angle": cos_th, "sin_observer_angle": sin_th,
                      "INVERSE_SQRT_3": sp.Symbol("ISQ3"), "RIM_INVERSE_SQRT_3": sp.Symbol("ISQ3"),
                      "THREE_TWO_THIRDS": sp.Symbol("T23"), "RIM_THREE_TWO_THIRDS": sp.Symbol("T23")})

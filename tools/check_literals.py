@@ -367,6 +367,17 @@ def main():
             body = body.replace("double y;", "")
             env = {"rimo_bessel_i": lambda nu, a: Bi(sp.nsimplify(nu), a), "rimo_bessel_jnu": lambda nu, a: Bj(sp.nsimplify(nu), a),
                    "rimo_bessel_ynu": lambda nu, a: By(sp.nsimplify(nu), a)}
+            # round 4: g comes from qr_g(st) (its literal branch is heyvaerts.rs:309, 406, checked here as that expression)
+            # and the four Bessel values of the large-g branch from jy_set(), whose literal branch hands back exactly
+            # these calls (oracle/rimo_heyvaerts.c jy_set)
+            qr_g_src = between(oh, "static double qr_g(const hey_state *st)", "\n}\n")
+            assert "return SQRT_8_OVER_3 * m_pow15(st->sigma - st->x) / m_sqrt(st->x);" in qr_g_src
+            jy_src = between(oh, "static void jy_set(", "\n}\n")
+            for line in ("*js = rimo_bessel_jnu(sigma, x);", "*jm1 = rimo_bessel_jnu(sigma - 1., x);", "*ys = rimo_bessel_ynu(sigma, x);",
+                         "*ym1 = want_ym1 ? rimo_bessel_ynu(sigma - 1., x) : 0.;"):
+                assert line in jy_src, line
+            env.update({"st": None, "qr_g": lambda _st: gsym, "js": Bj(sig, xx), "ys": By(sig, xx), "jm1": Bj(sig - 1, xx), "ym1": By(sig - 1, xx)})
+            body = body.replace("double js = 0., ys = 0., jm1 = 0., ym1 = 0.;", "").replace("double js, ys, jm1, ym1;", "")
             e = run_dev("X" + body + "\nEND", "X", "END", extra=env)
             same("%s, %s-g branch (heyvaerts.rs:302-373, 400-447) vs oracle/rimo_heyvaerts.c" % (fn, branch),
                  e["RESULT"].subs(sp.Symbol("g"), gsym) if False else e["RESULT"], ref)
