@@ -872,6 +872,36 @@ template <int PREC> struct RimMath {
     RIM_FN double cbrt_normal(double x) { return rim_cbrt_normal(x); }              /* bessel.c:180 pow(x, 1./3.) */
     RIM_FN double powexp_normal(double x, double y, double e) { return rim_powexp_normal(x, y, e); }
 };
+#if defined(RIM_F32_SMOOTH)
+/* Measurement build only (tools/build_variant.sh ... -DRIM_F32_SMOOTH; tools/f32_variant.py): the "smooth" fp32 variant VERDICT
+ * round 3 asked to have MEASURED -- the fp32-core value as a seed, one fp64 correction step that removes its 1e-7 noise:
+ * exp: y = y0 (1 + (x - log y0)); pow: y = y0 (1 + (y log x - log y0)).  The logarithms are the fp64 ones: a correction
+ * step is only as good as its residual. */
+RIM_FN double rim_exp_smooth(double x)
+{
+    const double y0 = rim_exp_f32core(x);
+    if (!(y0 >= 2.2250738585072014e-308) || !rim_isfinite(y0)) return y0;
+    return y0 * (1. + (x - rim_log_normal(y0)));
+}
+RIM_FN double rim_pow_smooth(double x, double y)
+{
+    const double y0 = rim_pow_f32core(x, y);
+    if (!(y0 >= 2.2250738585072014e-308) || !rim_isfinite(y0)) return y0;
+    return y0 * (1. + (y * rim_log_normal(x) - rim_log_normal(y0)));
+}
+template <> struct RimMath<1> {
+    RIM_FN double exp(double x) { return rim_exp_smooth(x); }
+    RIM_FN double exp_bounded(double x) { return rim_exp_smooth(x); }
+    RIM_FN double pow(double x, double y)
+    {
+        if (!(x > 2.3e-308) || !rim_isfinite(x) || y == 0.0 || !rim_isfinite(y)) return rim_pow(x, y);
+        return rim_pow_smooth(x, y);
+    }
+    RIM_FN double pow_normal(double x, double y) { return rim_pow_smooth(x, y); }
+    RIM_FN double cbrt_normal(double x) { return rim_cbrt_f32core(x); }
+    RIM_FN double powexp_normal(double x, double y, double e) { return rim_pow_smooth(x, y) * rim_exp_smooth(e); }
+};
+#else
 template <> struct RimMath<1> {
     RIM_FN double exp(double x) { return rim_exp_f32core(x); }
     RIM_FN double exp_bounded(double x) { return rim_exp_f32core(x); }
@@ -885,6 +915,7 @@ template <> struct RimMath<1> {
     RIM_FN double cbrt_normal(double x) { return rim_cbrt_f32core(x); }
     RIM_FN double powexp_normal(double x, double y, double e) { return rim_pow_f32core(x, y) * rim_exp_f32core(e); }
 };
+#endif
 #endif
 
 #endif /* RIM_DETMATH_H */

@@ -1255,7 +1255,9 @@ static int rim_precision_check(const rimphony_ctx *c, int kind, int precision)
 {
     if (precision == RIMPHONY_PRECISION_F64) return RIMPHONY_OK;
     if (precision != RIMPHONY_PRECISION_F32_INTEGRAND || !c || !c->f32_variant) return RIMPHONY_ENOTSUP;
+#if !defined(RIM_F32_SMOOTH)      // (the measurement build of the "smooth" variant serves all four kinds)
     if (kind == RIMPHONY_PITCHY_PL || kind == RIMPHONY_PITCHY_KAPPA) return RIMPHONY_ENOTSUP;
+#endif
     return RIMPHONY_OK;
 }
 
@@ -1364,6 +1366,10 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
             // the six Symphony coefficients with the fp32-core integrand (detmath.h); the Faraday pair below stays fp64
             // (kinds 2 and 3 were refused at the entry: RIMPHONY_ENOTSUP)
             if (kind == 0) rc = launch_symphony<0, 1>(c, a, st);
+#if defined(RIM_F32_SMOOTH)
+            else if (kind == 2) rc = launch_symphony<2, 1>(c, a, st);
+            else if (kind == 3) rc = launch_symphony<3, 1>(c, a, st);
+#endif
             else rc = launch_symphony<1, 1>(c, a, st);
         } else if (!c->sym_solo) {
             // the coefficients of a point that share their samples advance in lock-step on one wave

@@ -249,17 +249,20 @@ def test_against_literal_flavour_vectors(gpu_ctx, cfg):
 
 
 def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` without torchrun: the parent spawns the ranks before touching the GPU.  On this
-    1-GPU box the two ranks share cuda:0 (RIMPHONY_BENCH_REHEARSE=1, gloo), which exercises the launcher, the
-    interleaved sharding and the gather, not the speed."""
+    """`python bench.py --gpus 4` without torchrun: the parent spawns the ranks before touching the GPU.  On this
+    1-GPU box the four ranks share cuda:0 (RIMPHONY_BENCH_REHEARSE=1, gloo: one context owns the device, three run in
+    shared mode), which exercises the launcher, the interleaved sharding and the gather, not the speed.  (Four ranks, not
+    the eight of the scaling run: the box allows six processes on its card, this test runner included; the eight-rank
+    launcher / shard / gather path runs on the CPU in tests/test_host_side.py.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["RIMPHONY_BENCH_REHEARSE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--points", "128", "--side-rows", "0", "--cpu-sample", "0", "--no-parity"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0",
+                        "--points", "67", "--side-rows", "0", "--cpu-sample", "0", "--no-parity"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["n_gpus"] == 4 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["config"]["points_per_step_per_gpu"] == 67
 
 
 def test_bench_runs_the_rccl_path_in_a_world_of_one():
