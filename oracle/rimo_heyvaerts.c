@@ -477,6 +477,21 @@ static double deriv_of(hey_state *st, rimo_fn f, double x)
     return r;
 }
 
+/* The quasi-resonant marching loop (heyvaerts.rs:156-185) never tests keep_going while qr_val is 0: when every chunk
+ * contributes exactly 0 it marches for ever.  For the thermal distribution that happens to cold, high-frequency points:
+ * d f / d gamma = norm exp(-gamma / T) (-1 / T) has underflowed to exactly 0 and gamma only grows.  The step cap of this
+ * restatement turns "never returns" into NaN; where the loop is PROVABLY endless the cap is applied at once, as the kernels
+ * do (dev_heyvaerts.h hey_point_endless / hey_qr_is_endless -- the same test, both flavours): every sample of every later
+ * chunk has gamma >= (sigma - 3^(1/3) sigma^(2/3)) / (sigma0 sin theta) >= 760 T, and exp() is exactly 0 below -745.2. */
+static int qr_is_endless(const hey_state *st, double sigma_low)
+{
+    if (st->d->kind != RIMO_THERMAL_JUETTNER) return 0;
+    const double g0 = -760. / st->d->neg_inverse_t;
+    if (!(g0 > 0. && g0 < 1e300) || !(sigma_low >= 1.)) return 0;
+    const double c = rim_cbrt_normal(sigma_low);
+    return (sigma_low - 1.4422495703074083 * (c * c)) * st->dinv >= g0;
+}
+
 double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, double theta, rimo_counters *c)
 {
     hey_state st;
@@ -557,6 +572,9 @@ double rimo_heyvaerts(const rimo_dist *d, int coeff, int stokes, double s, doubl
                     if (delta_sigma < 1e6 * st.sigma0)
                         delta_sigma *= DELTA_SCALE_FACTOR;
                 }
+            }
+            else if (qr_is_endless(&st, sigma_low)) {
+                goto done;          /* provably endless: the step cap at once (see qr_is_endless) */
             }
             const double contrib = outer_integral(&st, qr_outer_integrand, sigma_low, sigma_low + delta_sigma);
             if (rim_isnan(contrib)) goto done;

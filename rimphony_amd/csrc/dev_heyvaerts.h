@@ -283,6 +283,7 @@ struct HeyPoint {
     double s, cos_th, sin_th, sigma0, sigma0_sq;
     double dinv;        // 1 / (sigma0 sin(theta)): gamma and the gamma-term of d f / d sigma MULTIPLY by it (round 4;
                         // heyvaerts.rs:197, 478 divide by sigma0 sin(theta) per sample -- the literal oracle still does)
+    double endless_gamma;   // a Lorentz factor beyond which d f / d gamma is exactly 0 for good (hey_point_endless); +inf: none known
     int stokes;
 };
 
@@ -292,6 +293,34 @@ RIM_DEV void hey_point_derive(HeyPoint &pt)
     pt.sigma0 = pt.s * pt.sin_th;
     pt.sigma0_sq = pt.sigma0 * pt.sigma0;
     pt.dinv = 1. / (pt.sigma0 * pt.sin_th);
+    pt.endless_gamma = RIM_INF;
+}
+
+// The quasi-resonant marching loop of the reference (heyvaerts.rs:156-185) only tests `keep_going` once qr_val is non-zero:
+// while every chunk contributes exactly 0 it marches on for ever.  For the thermal distribution that is what happens to
+// cold, high-frequency points (0.13 % of the rows of configs[2]'s table): d f / d gamma = norm exp(-gamma / T) (-1 / T) has
+// underflowed to exactly 0 on the whole first chunk and gamma only grows from there.  This restatement's step cap turned
+// "never returns" into NaN after 4096 such chunks (deviation 3) -- 4096 x 31 x 31 samples of exact
+// zeros per coefficient, the longest chains of the thermal table.  Where the loop is PROVABLY endless the cap is now
+// applied at once: endless_gamma = 760 T (rim_exp returns exactly 0 below -745.2; the margin covers every rounding of the
+// sample's gamma), and hey_qr_is_endless() holds when every sample of every later chunk has gamma >= endless_gamma:
+// gamma = (sigma - pomega cos(theta)) dinv >= (sigma - |pomega|) dinv >= (sigma - 3^(1/3) sigma^(2/3)) dinv, because
+// |pomega| <= sqrt(3^(2/3) sigma^(4/3) - sigma0^2) (heyvaerts.rs:270-272), and that bound grows with sigma for sigma >= 1.
+// Same value (NaN), same status (CHUNK_CAP); the deterministic AND the literal oracle apply the same test.
+template <int KIND>
+RIM_DEV void hey_point_endless(HeyPoint &pt, const DistParams &d)
+{
+    pt.endless_gamma = RIM_INF;
+    if (KIND == DIST_THERMAL_JUETTNER) {
+        const double g0 = -760. / d.neg_inverse_t;          // 760 T
+        if (g0 > 0. && g0 < 1e300) pt.endless_gamma = g0;
+    }
+}
+RIM_DEV bool hey_qr_is_endless(const HeyPoint &pt, double sigma_low)
+{
+    if (!(sigma_low >= 1.) || !(pt.endless_gamma < 1e300)) return false;
+    const double c = rim_cbrt_normal(sigma_low);
+    return (sigma_low - 1.4422495703074083 * (c * c)) * pt.dinv >= pt.endless_gamma;
 }
 
 struct HeyCoord { double sigma, pomega, x, gamma, mu; };

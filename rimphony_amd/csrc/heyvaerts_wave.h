@@ -73,7 +73,7 @@ __device__ __forceinline__ void hey_start_deriv(HeyTask &T, double x)
 __device__ __forceinline__ void hey_fail(HeyTask &T) { T.failed = 1; T.stage = HS_DONE; }
 
 // head of the marching loop of the current stage (the `while keep_going` tests of heyvaerts.rs:102,134,161)
-__device__ __forceinline__ void hey_loop_head(HeyTask &T)
+__device__ __forceinline__ void hey_loop_head(const HeyPoint &pt, HeyTask &T)
 {
     if (++T.steps > RIM_HEY_MAX_STEPS) { T.status |= ST_CHUNK_CAP; hey_fail(T); return; }
     if (T.stage == HS_NR_RIGHT) {
@@ -83,6 +83,7 @@ __device__ __forceinline__ void hey_loop_head(HeyTask &T)
         hey_start_deriv(T, T.pomega_left);
     } else {   // HS_QR
         if (T.qr_val != 0.) hey_start_deriv(T, T.sigma_low);
+        else if (hey_qr_is_endless(pt, T.sigma_low)) { T.status |= ST_CHUNK_CAP; hey_fail(T); }      // dev_heyvaerts.h
         else hey_start_chunk(T, T.sigma_low, T.sigma_low + T.delta_sigma);
     }
 }
@@ -296,7 +297,7 @@ __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g,
         T.nr_val = contrib;
         T.stage = HS_NR_RIGHT;
         T.steps = 0;
-        hey_loop_head(T);
+        hey_loop_head(pt, T);
         return;
     }
     bool keep_going = true;
@@ -305,7 +306,7 @@ __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g,
         T.nr_val += contrib;
         T.pomega_right += T.delta_right;
         if (!keep_going) { T.stage = HS_NR_LEFT; T.steps = 0; }
-        hey_loop_head(T);
+        hey_loop_head(pt, T);
     } else if (T.stage == HS_NR_LEFT) {
         keep_going = rim_fabs(contrib / T.nr_val) > RIM_HEY_TOL;
         T.nr_val += contrib;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g,
             T.sigma_low = rust_max(pt.sigma0, RIM_INVERSE_SQRT_3 * rim_pow(pt.sigma0, 1.5));
             T.delta_sigma = pt.sigma0;
         }
-        hey_loop_head(T);
+        hey_loop_head(pt, T);
     } else {   // HS_QR
         if (T.qr_val != 0.) keep_going = rim_fabs(contrib / T.qr_val) > RIM_HEY_TOL;
         T.qr_val += contrib;
@@ -328,7 +329,7 @@ __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g,
                 / (RIM_MASS_ELECTRON * (ssin * ssin));
             T.stage = HS_DONE;
         } else {
-            hey_loop_head(T);
+            hey_loop_head(pt, T);
         }
     }
 }

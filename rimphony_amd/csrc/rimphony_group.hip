@@ -65,7 +65,7 @@ struct HeyGroupProblem {
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
         c.hc = hey_consts();
-        c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.dinv = 0.; c.pt.stokes = STOKES_Q;
+        c.pt.s = 0.; c.pt.cos_th = 0.; c.pt.sin_th = 0.; c.pt.sigma0 = 0.; c.pt.sigma0_sq = 0.; c.pt.dinv = 0.; c.pt.endless_gamma = RIM_INF; c.pt.stokes = STOKES_Q;
     }
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, unsigned, Ctx &c, double &norm)
     {
@@ -85,6 +85,8 @@ struct HeyGroupProblem {
         c.d.inv_gamma_cutoff = uni(c.d.inv_gamma_cutoff);
         c.d.inv_kappa_width = uni(c.d.inv_kappa_width);
         c.d.neg_inverse_t = uni(c.d.neg_inverse_t);
+        hey_point_endless<KIND>(pt, c.d);
+        pt.endless_gamma = uni(pt.endless_gamma);
     }
     static __device__ __forceinline__ HeyPoint member_point(const Ctx &c, int slot)
     { HeyPoint pt = c.pt; pt.stokes = hey_slot_stokes(slot); return pt; }

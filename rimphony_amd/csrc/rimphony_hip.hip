@@ -173,6 +173,8 @@ struct HeyvaertsProblem {
         c.d.inv_gamma_cutoff = uni(c.d.inv_gamma_cutoff);
         c.d.inv_kappa_width = uni(c.d.inv_kappa_width);
         c.d.neg_inverse_t = uni(c.d.neg_inverse_t);
+        hey_point_endless<KIND>(pt, c.d);
+        pt.endless_gamma = uni(pt.endless_gamma);
     }
     static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { hey_begin(c.pt, T); }
     static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }

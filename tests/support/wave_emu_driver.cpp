@@ -52,7 +52,7 @@ static void lane_body(EmuTask *t)
         __shared__ HeyTask s_hpark;
         HeyPoint hp;
         hp.s = pt.s; hp.sin_th = pt.sin_th; hp.cos_th = pt.cos_th;
-        hey_point_derive(hp); hp.stokes = t->stokes;
+        hey_point_derive(hp); hey_point_endless<KIND>(hp, d); hp.stokes = t->stokes;
         const HeyConsts hc = hey_consts();
         val = heyvaerts_coefficient<KIND>(hp, d, hc, g, inner, outer, &s_hpark, &s_qpark, st);
     } else {
@@ -252,6 +252,7 @@ static void hey_group_lane_body(EmuGroupTask *t)
     DistParams d;
     for (int k = 0; k < 5; k++) d.par[k] = t->par[k];
     dist_prepare<KIND>(d, t->norm);
+    hey_point_endless<KIND>(hp, d);
     const HeyConsts hc = hey_consts();
     double vals[RIM_GROUP] = { 0, 0, 0, 0 };
     int stats[RIM_GROUP] = { 0, 0, 0, 0 };
