@@ -57,12 +57,6 @@ struct SymArgs {
     unsigned long long *work;       // optional [n][8]: integrand samples spent on each coefficient (null: not counted)
     unsigned long long idle_ticks;  // wall_clock64 ticks after which a helper that has found nothing leaves (2 s)
     unsigned long long owner_ticks; // ... after which an owner stops waiting for helpers and recomputes its batch (120 s)
-    // Early help (round 4, Faraday kernel; 0 = off): the last `early_helpers` waves of the grid never fetch a task -- they
-    // are helpers from the start of the launch --, and an owner whose task is past `early_batches` batches publishes
-    // its batches to them while the queue is still full: a chain of thousands of sequential batches (one outer quadrature
-    // on its way to GSL's iteration limit) then overlaps with the bulk of the launch instead of following it.
-    unsigned early_helpers;
-    int early_batches;
 };
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };

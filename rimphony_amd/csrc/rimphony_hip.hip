@@ -125,7 +125,7 @@ struct SymphonyProblem {
     struct Ctx { SymPoint pt; DistParams d; };
     typedef TaskState Task;
     typedef QagPark Park;
-    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0, EXTRA_LDS_DOUBLES = 1, EARLY_HELP = 0 };
+    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0, EXTRA_LDS_DOUBLES = 1 };
     static __device__ __forceinline__ void init(const SymArgs &, Ctx &, double *) {}
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     { load_context<KIND>(a, i, slot, c.pt, c.d, norm); }
@@ -150,7 +150,7 @@ struct HeyvaertsProblem {
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
     typedef HeyTask Task;
     typedef QagParkBase Park;
-    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 1, EARLY_HELP = 1 };
+    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 1 };
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
         c.hc = hey_consts();
@@ -244,20 +244,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     bool board_dead = false;               // this wave once gave up waiting for helpers: it never publishes again (below)
     unsigned last_hint = 0;                // lane 0: the hint whose batch this wave has already seen exhausted
 
-    // early help: the last a.early_helpers waves are helpers from the start (they never fetch a task)
-    const bool dedicated = P::EARLY_HELP && a.early_helpers != 0u && a.board != nullptr &&
-                           (unsigned) blockIdx.x + a.early_helpers >= (unsigned) gridDim.x;
-    if (dedicated) {
-        helper = true;
-        counted_idle = true;
-        if (lane == 0) {
-            __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // issue priorities: 3 a task that recruits early helpers and those helpers (its chain is the launch's critical path),
-    // 2 every other owner, 0 the helpers of the tail
-    if (dedicated) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(3);
     for (;;) {
         SymBatch B;
         B.req_n = 0.; B.req_lobe = 0; B.req_active = false; B.n_req = 0; B.phase = PH_DONE;
@@ -309,16 +296,13 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (lane == 0) s_park = T0;
                 __syncthreads();
                 have_task = true;
-                __builtin_amdgcn_s_setprio(2);
             }
             bool finished;
-            int task_batches = 0;
             {
                 typename P::Task T = s_park;
                 P::uniformize(T);
                 if (!P::done(T)) P::post(cx, g, outer, T, B);
                 finished = P::done(T);
-                task_batches = T.batches;
                 if (finished) {
                     int st = 0;
                     const double val = P::result(cx, T, st);
@@ -342,23 +326,18 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             if (finished) { have_task = false; continue; }
             mask = wv_ballot(B.req_active);
 
-            // publish the batch when some wave is idle -- or, before the queue is empty, when this task is long enough to
-            // recruit the launch's early helpers (they may all be busy with its previous batch right now: publish anyway)
-            const bool long_task = P::EARLY_HELP && a.early_helpers != 0u && task_batches > a.early_batches;
-            if (long_task) __builtin_amdgcn_s_setprio(3);
-            unsigned idle = 0, act = 1, exhausted = 0;
+            // publish the batch when some wave is idle
+            unsigned idle = 0, act = 1;
             if (lane == 0 && a.board) {
-                exhausted = __hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (exhausted || long_task) {
+                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     idle = __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
-            exhausted = (unsigned) __builtin_amdgcn_readfirstlane((int) exhausted);
             const int cnt = __builtin_popcountll(mask);
-            shared = (idle != 0 || (long_task && !exhausted && a.board != nullptr)) && cnt >= 2 && !board_dead;
+            shared = idle != 0 && cnt >= 2 && !board_dead;
             if (shared) {
                 seq += 1;
                 src_seq = seq;
@@ -381,8 +360,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 drain_vmem();          // the claim word is out before anybody can see the hint
                 __syncthreads();
                 {
-                    // (before the queue is empty the only listeners are the early helpers: every hint line)
-                    const unsigned span = exhausted ? hint_span(act) : 1u;
+                    const unsigned span = hint_span(act);
                     const unsigned channel = ((unsigned) blockIdx.x + seq) & (span - 1u);
                     if (((unsigned) lane & (span - 1u)) == channel)
                         __hip_atomic_store(&hints[(unsigned) lane * BOARD_HINT_STRIDE], (seq << 16) | ((unsigned) blockIdx.x + 1u),
@@ -430,13 +408,13 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 // sizes it so that it is), the waves waiting for a slot get one instead of being waited for.
                 const unsigned long long now = wall_clock64();
                 if (idle_since == 0) idle_since = now;
-                else if (now - idle_since > (dedicated ? 8ull * a.idle_ticks : a.idle_ticks)) {
+                else if (now - idle_since > a.idle_ticks) {
                     if (counted_idle && lane == 0)
                         __hip_atomic_fetch_sub(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 for (int w = 0; w < backoff; w++) __builtin_amdgcn_s_sleep(127);
-                if (backoff < (dedicated ? 4 : 16)) backoff *= 2;      // an early helper's owner is waiting for it: look more often
+                if (backoff < 16) backoff *= 2;
                 continue;
             }
             h &= 0xffffu;
@@ -831,8 +809,6 @@ struct rimphony_ctx {
     int lock_fd;
     unsigned long long ticks_per_s;  // wall_clock64 rate of the device
     unsigned long long owner_wait_ticks;   // how long an owner waits for its helpers before recomputing a batch itself
-    unsigned early_helpers;                // RIMPHONY_EARLY_HELPERS: waves of the Faraday grid that are helpers from the start (0: off)
-    int early_batches;                     // RIMPHONY_EARLY_BATCHES: a Faraday task past this many batches recruits them
     // successive batch calls of a context share its workspace: each call's stream waits for the previous call's
     // work (ev_batch), and the calls themselves are serialised by mu
     hipEvent_t ev_batch;
@@ -957,8 +933,6 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_F32_VARIANT"); c->f32_variant = (e && e[0] == '1'); }
-    { const char *e = getenv("RIMPHONY_EARLY_HELPERS"); c->early_helpers = e ? (unsigned) strtoul(e, nullptr, 10) : RIM_EARLY_HELPERS_DEFAULT; }
-    { const char *e = getenv("RIMPHONY_EARLY_BATCHES"); c->early_batches = e ? atoi(e) : 192; }
     { const char *e = getenv("RIMPHONY_FARADAY_GROUP"); c->faraday_group = (e && e[0] == '1'); }
     c->shared_mode = take_device_lock(device, &c->lock_fd);
     if (c->shared_mode) {
@@ -1152,11 +1126,6 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
     b.idle_ticks = 2ull * c->ticks_per_s;
     b.owner_ticks = c->owner_wait_ticks;
-    // early help only where there is a bulk to overlap with (many more tasks than waves), never in shared mode
-    b.early_helpers = 0;
-    b.early_batches = c->early_batches;
-    if (P::EARLY_HELP && b.board && !c->shared_mode && c->early_helpers && ntasks >= 4ull * grid && grid >= 16u * c->early_helpers)
-        b.early_helpers = c->early_helpers;
     // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
     hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);
@@ -1347,8 +1316,6 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
     if (rc) return rc;
 
     SymArgs a;
-    a.early_helpers = 0;        // (set per launch by launch_coop)
-    a.early_batches = 0;
     a.pp = pp;
     a.s = d_s;
     a.theta = d_theta;

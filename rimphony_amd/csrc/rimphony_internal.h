@@ -34,11 +34,6 @@
                                  // pitchy-kappa points, whose tail is sequential -- 5 kept)
 #endif
 
-// waves of the Faraday kernel's grid that are helpers from the start of a launch (RIMPHONY_EARLY_HELPERS overrides; 0 = off)
-#ifndef RIM_EARLY_HELPERS_DEFAULT
-#define RIM_EARLY_HELPERS_DEFAULT 0
-#endif
-
 #if defined(RIM_PROF)
 #define RIM_DYN_LDS 256             // the region timers accumulate in dynamic LDS
 #else
