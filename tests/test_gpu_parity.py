@@ -263,6 +263,22 @@ def test_faraday_bit_exact(gpu_ctx, oracle, cfg, n):
     _symphony_parity(gpu_ctx, oracle, cfg, n, 0xC0)
 
 
+def test_endless_thermal_marching_loops_end_at_once_with_the_caps_status(gpu_ctx, oracle):
+    """Cold, high-frequency thermal points whose quasi-resonant part is exactly 0: the reference's marching loop never ends
+    there (heyvaerts.rs:156-185 tests keep_going only once qr_val != 0); this build applies its step cap as soon as the
+    loop is PROVABLY endless (dev_heyvaerts.h hey_qr_is_endless).  Row 51111 of the thermal table is one (found as the
+    longest chain of the table, profiles/r4_launch_tails.txt): both Faraday slots NaN with status CHUNK_CAP | NONFINITE, after
+    a few hundred thousand samples instead of the four million the 4096-step cap took, and the oracle agrees -- values,
+    and sample counts (the work counters would show a loop that ran on)."""
+    kind, mask, s, th, params = workload.make_batch("cfg3_thermal_8", 4, start=51109)
+    out, st, work = gpu_ctx.compute_batch(kind, s, th, params, 0xC0, want_status=True, want_work=True)
+    assert np.isnan(out[2, 6:]).all() and (st[2, 6:] == (4 | 16)).all(), (out[2], st[2])
+    assert (work[2, 6:] < 1000000).all() and (work[2, 6:] > 100000).all(), work[2]
+    ref, ctr = oracle_bind.batch(oracle, kind, s, th, params, 0xC0, nthreads=4, want_counters=True)
+    report_mismatch("thermal rows around an endless loop", out[:, 6:], ref[:, 6:])
+    assert int(work[:, 6:].sum()) == ctr["integrand_evals"]
+
+
 def test_faraday_known_answers_on_gpu(gpu_ctx):
     """The reference's four 1 % Faraday fixtures through the HIP path (power_law.rs:209-240,
     thermal_juettner.rs:174-210)."""
