@@ -626,8 +626,26 @@ __global__ void board_init_kernel(unsigned *flags, unsigned active)
 // ------------------------------------------------------------------------------
 #define ORDER_BUCKETS 32
 
-__device__ __forceinline__ int order_bucket(double s, double theta, const double *gmin, size_t i)
+__device__ __forceinline__ int order_bucket(double s, double theta, const double *gmin, const double *temp, size_t i)
 {
+    // Thermal distribution: the long tasks are the COLD, LOW-FREQUENCY, SMALL-ANGLE points, not the large-s ones -- there
+    // j_V / alpha_V march through ~300 batches of the tail integral before GSL's round-off detector ends them (NaN, as in
+    // the reference), ten times the table's median.  Measured on 65536 rows of configs[2]'s table with the per-coefficient
+    // batch counts of a -DRIM_TAIL_DIAG build (round 4): s sin(theta) T^2 < 1 holds for 18 % of the rows and 95 % of the
+    // coefficients of 200 batches and more (< 0.01: 3 % of the rows, 43 % of them, 92 % pure).  They go first; with the
+    // large-s-first order they started last and were 12 % of a 65536-row launch of the Symphony groups.
+    if (temp) {
+        double sn, cs;
+        rim_sincos(theta, &sn, &cs);
+        const double t = temp[i];
+        const double key = s * rim_fabs(sn) * (t * t);
+        if (key < 0.01) return 0;
+        if (key < 0.1) return 1;
+        if (key < 1.) return 2;
+        const int e = (int) ((rim_bits(s) >> 52) & 0x7ff) - 1023;
+        const int b = 17 - e;
+        return b < 3 ? 3 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
+    }
     // Points whose 30 discrete harmonics all lie below gamma_min (power-law families) start the n
     // integration from zero and must resolve the onset at gamma_min inside one wide chunk: they are
     // 100-1000x the mean cost (and usually end in a GSL round-off failure, as in the reference).
@@ -645,10 +663,10 @@ __device__ __forceinline__ int order_bucket(double s, double theta, const double
     return b < 1 ? 1 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
 }
 
-__global__ void order_hist_kernel(const double *s, const double *theta, const double *gmin, size_t n, unsigned *hist)
+__global__ void order_hist_kernel(const double *s, const double *theta, const double *gmin, const double *temp, size_t n, unsigned *hist)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[order_bucket(s[i], theta[i], gmin, i)], 1u);
+    if (i < n) atomicAdd(&hist[order_bucket(s[i], theta[i], gmin, temp, i)], 1u);
 }
 
 __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, one thread
@@ -659,11 +677,11 @@ __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, 
     }
 }
 
-__global__ void order_scatter_kernel(const double *s, const double *theta, const double *gmin, size_t n,
+__global__ void order_scatter_kernel(const double *s, const double *theta, const double *gmin, const double *temp, size_t n,
                                      unsigned *offsets, unsigned *perm)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i], theta[i], gmin, i)], 1u)] = (unsigned) i;
+    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i], theta[i], gmin, temp, i)], 1u)] = (unsigned) i;
 }
 
 // fills the slots that were not selected (or not yet available) with NaN
@@ -1333,9 +1351,10 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
         const unsigned nb = (unsigned) ((n + 255) / 256);
         HIP_TRY(hipMemsetAsync(hist, 0, ORDER_BUCKETS * sizeof(unsigned), st));
         const double *gmin = (kind == RIMPHONY_POWER_LAW) ? pp.p[1] : (kind == RIMPHONY_PITCHY_PL) ? pp.p[2] : nullptr;
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, n, hist);
+        const double *temp = (kind == RIMPHONY_THERMAL_JUETTNER) ? pp.p[0] : nullptr;
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, temp, n, hist);
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), RIM_DYN_LDS, st, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, n, hist, c->d_perm);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, temp, n, hist, c->d_perm);
         HIP_TRY(hipGetLastError());
         a.perm = c->d_perm;
     }

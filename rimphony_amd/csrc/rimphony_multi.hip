@@ -30,12 +30,25 @@ extern "C" int rimphony_batch_compute_multi_device(rimphony_ctx *const *ctxs, in
     for (int r = 0; r < n_ctx; r++)
         if (!ctxs[r] || (n_local[r] && (!d_s[r] || !d_theta[r] || !d_params[r] || !d_out[r]))) return RIMPHONY_EINVAL;
     // launches are asynchronous: every device is busy before the first one is waited for
-    for (int r = 0; r < n_ctx; r++) {
+    int launched = 0, launch_rc = RIMPHONY_OK;
+    std::string launch_err;
+    for (int r = 0; r < n_ctx; r++, launched++) {
         if (n_local[r] == 0) continue;
-        const int rc = rimphony_batch_compute_device_ex(ctxs[r], dist_kind, n_local[r], d_s[r], d_theta[r], d_params[r], coeff_mask,
-                                                        precision, d_out[r], d_status ? d_status[r] : nullptr,
-                                                        d_work ? d_work[r] : nullptr, streams ? streams[r] : nullptr);
-        if (rc) return rc;
+        launch_rc = rimphony_batch_compute_device_ex(ctxs[r], dist_kind, n_local[r], d_s[r], d_theta[r], d_params[r], coeff_mask,
+                                                     precision, d_out[r], d_status ? d_status[r] : nullptr,
+                                                     d_work ? d_work[r] : nullptr, streams ? streams[r] : nullptr);
+        if (launch_rc) { launch_err = rimphony_last_error(); break; }
+    }
+    if (launch_rc) {
+        // a context refused its launch: the devices before it are already computing into the caller's buffers -- wait for
+        // them whatever `synchronize` says, so that "the call failed" also means "nothing is still running"
+        for (int r = 0; r < launched; r++) {
+            int dev = -1;
+            if (n_local[r] == 0 || rimphony_ctx_device(ctxs[r], &dev) != RIMPHONY_OK) continue;
+            if (hipSetDevice(dev) == hipSuccess) (void) hipStreamSynchronize(streams ? (hipStream_t) streams[r] : (hipStream_t) 0);
+        }
+        if (!launch_err.empty()) rim_set_last_error("rimphony_batch_compute_multi_device", launch_err.c_str());
+        return launch_rc;
     }
     if (synchronize) {
         int dev0 = 0;

@@ -340,7 +340,8 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     if ((booknow >> m) & 1u) {
                         RIM_PROF_T(t_ab);
                         const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
-                        const bool fin = group_book(M, st, g, cur, sel4(m, idx0, idx1, idx2, idx3), a_i, b_i,
+                        // (the entry indices are wave-uniform but come back from scratch as vector registers: say so)
+                        const bool fin = group_book(M, st, g, cur, uni(sel4(m, idx0, idx1, idx2, idx3)), a_i, b_i,
                                                     r.result, r.abserr, readlane_d(r.result, 32), readlane_d(r.abserr, 32),
                                                     (ne & 1ull) && ((ne >> 32) & 1ull), r.result, r.abserr, epsrel, limit);
                         n_samp_all += 62u;
@@ -350,7 +351,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     } else {
                         // file the children's sums in the member's stash (a free place, else the next one in turn)
                         RIM_PROF_T(t_file);
-                        const int idx = sel4(m, idx0, idx1, idx2, idx3);
+                        const int idx = uni(sel4(m, idx0, idx1, idx2, idx3));
                         const unsigned long long freep = wv_ballot(lane < RIM_STASH && M->sk[lane & (RIM_STASH - 1)] < 0);
                         const int pos = freep ? __builtin_ffsll((long long) freep) - 1 : uni(M->snext);
                         wv_sync();

@@ -14,7 +14,7 @@ four eight-coefficient literal tables, Faraday slots only, and tabulates the dis
   * with ALL BUT ONE reverted (what that form alone costs on an otherwise literal evaluation),
   * and with any further masks given on the command line (--mask 0x.. or names joined by +).
 
-CPU only.  python tools/faraday_tail_attribution.py [--threads N] [--rows N] [--mask NAME+NAME ...] [--out FILE]
+CPU only.  python tools/faraday_tail_attribution.py [--threads N] [--rows N] [--tables cfg,..] [--mask NAME+NAME ...] [--out FILE]
 Results are cached per (table, mask, rows) in gpurun_out/attr_cache.json so that a run can be resumed."""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,6 +67,7 @@ def main():
     argv = sys.argv[1:]
     threads, rows, extra, out_path = 7, 2048, [], os.path.join(ROOT, "profiles", "r4_faraday_tail_attribution.txt")
     only_extra = False
+    only_tables = None
     while argv:
         a = argv.pop(0)
         if a == "--threads": threads = int(argv.pop(0))
@@ -74,6 +75,7 @@ def main():
         elif a == "--mask": extra.append(parse_mask(argv.pop(0)))
         elif a == "--out": out_path = argv.pop(0)
         elif a == "--only-extra": only_extra = True
+        elif a == "--tables": only_tables = argv.pop(0).split(",")
         else: raise SystemExit("unknown argument " + a)
     L = oracle_bind.load("attr")
     L.rimo_set_attr_mask.restype = None
@@ -87,6 +89,8 @@ def main():
     os.makedirs(os.path.dirname(cache_path), exist_ok=True)
     cache = json.load(open(cache_path)) if os.path.exists(cache_path) else {}
     for cfg, start in TABLES:
+        if only_tables and cfg not in only_tables:
+            continue
         kind, mask8, s, th, params = workload.make_batch(cfg, rows, start=start)
         z = np.load(os.path.join(ROOT, "tests", "golden", "literal_%s.npz" % cfg))
         assert int(z["start"]) == start and int(z["n"]) >= rows
