@@ -57,6 +57,19 @@ struct SymArgs {
     unsigned long long *work;       // optional [n][8]: integrand samples spent on each coefficient (null: not counted)
     unsigned long long idle_ticks;  // wall_clock64 ticks after which a helper that has found nothing leaves (2 s)
     unsigned long long owner_ticks; // ... after which an owner stops waiting for helpers and recomputes its batch (120 s)
+    // Early help for the launch's longest chain (Faraday kernel; early_squad = 0: off).  A task's batches are sequential
+    // (an outer quadrature on its way to GSL's iteration limit: thousands of them), and while the queue is full its owner
+    // evaluates every batch alone -- ~10 ms each -- so the chain is still young when the queue runs dry and the launch
+    // then waits for it.  `early_squad` waves of the grid (blocks k * early_stride) never fetch a task: they are helpers
+    // from the start.  An owner whose outer quadrature has grown past `early_min` subintervals enters that size in
+    // flags[CHAMP] (atomic max); the one task that holds the maximum -- the CHAMPION -- publishes its batches to the squad
+    // while the queue is still full, and gives the title back when its quadrature ends.  A quadrature that converges
+    // holds the title for a few batches at most (the squad serves it and it is soon over); the one that is on its way to
+    // GSL's limit outgrows every other, keeps the title and advances at the pace of the cooperative tail (~0.25 ms a
+    // batch) alongside the bulk instead of after it.  Who evaluates a request never changes its value: tables are bit-identical.
+    unsigned early_squad, early_stride;
+    unsigned early_classes;     // 1, 2 or 4 titles (64 waves of the squad each): that many long quadratures are served side by side
+    int early_min;
 };
 
 __constant__ int c_slot_coeff[8] = { 0, 1, 0, 1, 0, 1, 2, 2 };
@@ -121,7 +134,8 @@ __device__ __forceinline__ unsigned bget(const unsigned *p) { return __hip_atomi
 #define BOARD_FLAG_EXHAUSTED 0
 #define BOARD_FLAG_ACTIVE 32
 #define BOARD_FLAG_IDLE 64
-#define BOARD_HINTS 96          // 64 hint lines (stride 32 words): (seq << 16) | (slot + 1) of a published batch
+#define BOARD_FLAG_CHAMP 96      // early help: (size << 16) | (block + 1) of the longest outer quadrature in progress
+#define BOARD_HINTS 224         // (four title lines: 96, 128, 160, 192) 64 hint lines (stride 32 words): (seq << 16) | (slot + 1) of a published batch
 #define BOARD_HINT_STRIDE 32
 #define BOARD_FLAG_WORDS (BOARD_HINTS + 64 * BOARD_HINT_STRIDE)
 

@@ -125,11 +125,12 @@ struct SymphonyProblem {
     struct Ctx { SymPoint pt; DistParams d; };
     typedef TaskState Task;
     typedef QagPark Park;
-    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0, EXTRA_LDS_DOUBLES = 1 };
+    enum : unsigned long long { QUEUE = 0, WAVES = RIM_SYM_WAVES, HB_TAG = 0, EXTRA_LDS_DOUBLES = 1, EARLY_HELP = 0, EARLY_SQUAD = 0 };
     static __device__ __forceinline__ void init(const SymArgs &, Ctx &, double *) {}
     static __device__ __forceinline__ void load(const SymArgs &a, size_t i, int slot, Ctx &c, double &norm)
     { load_context<KIND>(a, i, slot, c.pt, c.d, norm); }
     static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { sym_begin(c.pt, T); }
+    static __device__ __forceinline__ int early_metric(const Task &) { return 0; }
     static __device__ __forceinline__ void uniformize(Task &T) { task_uniformize(T); }
     static __device__ __forceinline__ bool done(const Task &T) { return T.phase == PH_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
@@ -150,7 +151,14 @@ struct HeyvaertsProblem {
     struct Ctx { HeyPoint pt; DistParams d; HeyConsts hc; };
     typedef HeyTask Task;
     typedef QagParkBase Park;
-    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 1 };
+    // EARLY_SQUAD: the default size of the squad that serves the longest outer quadrature from the start of a launch
+    // (coop_common.h).  Outer quadratures that run to GSL's limit of 4096 bisections occur on the power-law table (one
+    // task in ~1e5: 4122 / 3775 batches -- one title, 64 waves) and on the pitchy-kappa table (four of 2844 .. 4132
+    // batches among the first 16793 rows and a dozen of 300 .. 760 -- four titles, 256 waves); the thermal table's long
+    // chains were the endless marching loops that hey_qr_is_endless() now ends at once, the pitchy power-law table has
+    // none past 244 batches -- there the squad would only cost its share of the grid.
+    enum : unsigned long long { QUEUE = 4, WAVES = RIM_HEY_WAVES, HB_TAG = 1ull << 62, EXTRA_LDS_DOUBLES = 1, EARLY_HELP = 1,
+                                EARLY_SQUAD = KIND == DIST_POWER_LAW ? RIM_EARLY_SQUAD_DEFAULT : KIND == DIST_PITCHY_KAPPA ? 4 * RIM_EARLY_SQUAD_DEFAULT : 0 };
     static __device__ __forceinline__ void init(const SymArgs &a, Ctx &c, double *extra_lds)
     {
         c.hc = hey_consts();
@@ -177,6 +185,11 @@ struct HeyvaertsProblem {
         pt.endless_gamma = uni(pt.endless_gamma);
     }
     static __device__ __forceinline__ void begin(const Ctx &c, Task &T) { hey_begin(c.pt, T); }
+    // what a task competes for early help with: the subintervals of the outer quadrature in progress (0 outside one).
+    // A quadrature that converges stays below a few dozen; one on its way to GSL's limit of 4096 (heyvaerts.rs:82-83)
+    // adds one per batch, for thousands of batches.
+    static __device__ __forceinline__ int early_metric(const Task &T)
+    { return (T.phase == HP_QAG_BISECT || T.phase == HP_QAG_FIRST) ? T.oq.size : 0; }
     static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
@@ -244,7 +257,27 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     bool board_dead = false;               // this wave once gave up waiting for helpers: it never publishes again (below)
     unsigned last_hint = 0;                // lane 0: the hint whose batch this wave has already seen exhausted
 
-    __builtin_amdgcn_s_setprio(3);
+    // early help for the launch's longest chain (coop_common.h, SymArgs::early_squad)
+    // (early_classes titles, each with its own 64 waves of the squad -- the ones that listen to the hint lines l with
+    // l & (classes - 1) == title.  A task competes for one title at a time, starting with block & (classes - 1); when a
+    // longer quadrature holds that one it moves to the title with the shortest holder, so that the titles end up with
+    // the `classes` longest quadratures in progress and that many chains are served side by side.  Measured and not kept:
+    // every champion publishing to the whole squad, eight titles on 256 waves -- the hint traffic slowed the bulk.)
+    unsigned title = (unsigned) blockIdx.x & (a.early_classes - 1u);
+    unsigned *const flag_champ0 = a.board_flags + BOARD_FLAG_CHAMP;
+    const bool early_on = P::EARLY_HELP && a.early_squad != 0u && a.board != nullptr;
+    const bool squad = early_on && (unsigned) blockIdx.x % a.early_stride == 0u && (unsigned) blockIdx.x / a.early_stride < a.early_squad;
+    unsigned champ_mine = 0;               // the word this wave last entered in flags[CHAMP] (0: none)
+    bool champion = false;                 // ... and it was the maximum: this task publishes while the queue is full
+    bool seen_exhausted = false;           // (squad) the queue has run dry: from here on an ordinary helper of the tail
+#if defined(RIM_TAIL_DIAG)
+    unsigned long long task_t0 = 0;
+    unsigned n_champ_batches = 0;
+#endif
+
+    // issue priorities: 3 the champion and the squad that serves it (the chain is the launch's critical path), 2 every
+    // other owner, 0 the helpers of the tail
+    __builtin_amdgcn_s_setprio(2);
     for (;;) {
         SymBatch B;
         B.req_n = 0.; B.req_lobe = 0; B.req_active = false; B.n_req = 0; B.phase = PH_DONE;
@@ -256,21 +289,26 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         if (!helper) {
             // ---------- owner: next batch of the current task (fetching a task first if needed) ----------
             if (!have_task) {
-                const unsigned long long t = wave_next_task(queue, lane);
+                // (a wave of the squad never fetches a task: it becomes a helper right here, without touching the queue --
+                // the host left it out of flags[ACTIVE])
+                const unsigned long long t = squad ? ~0ull : wave_next_task(queue, lane);
                 if (t >= ntasks) {
                     helper = true;
                     if (lane == 0) {
+                        if (!squad) {
 #if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when did the queue run dry, when did the launch end)
-                        atomicCAS(a.queue + (P::QUEUE ? 10 : 12), 0ull, wall_clock64());
+                            atomicCAS(a.queue + (P::QUEUE ? 10 : 12), 0ull, wall_clock64());
 #endif
-                        __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(flag_exhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_sub(flag_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         if (a.board) __hip_atomic_fetch_add(flag_idle, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     counted_idle = true;      // flags[IDLE] = helper waves that are not evaluating a request
                     // Helpers run below the issue priority of waves that own a task: an owner's serial
-                    // bookkeeping between batches is the critical path of the tail.
-                    __builtin_amdgcn_s_setprio(0);
+                    // bookkeeping between batches is the critical path of the tail.  (The squad keeps the champion's
+                    // priority until the queue is dry.)
+                    if (squad) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
                     if (!a.board) break;     // cooperation disabled
                     continue;
                 }
@@ -296,13 +334,18 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (lane == 0) s_park = T0;
                 __syncthreads();
                 have_task = true;
+#if defined(RIM_TAIL_DIAG)
+                task_t0 = wall_clock64();
+#endif
             }
             bool finished;
+            int task_batches = 0;            // (the task's early-help metric after this post)
             {
                 typename P::Task T = s_park;
                 P::uniformize(T);
                 if (!P::done(T)) P::post(cx, g, outer, T, B);
                 finished = P::done(T);
+                task_batches = P::early_metric(T);
                 if (finished) {
                     int st = 0;
                     const double val = P::result(cx, T, st);
@@ -311,6 +354,10 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     if (lane == 0) atomicMax(a.queue + (P::QUEUE ? 15 : 14), ((unsigned long long) T.batches << 40) | ((unsigned long long) own_i & 0xffffffffffull));
                     if (lane == 0) {
                         a.out[own_i * 8 + own_slot] = val;
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when a chain of >= 512 batches began and ended -- the last one to end is reported)
+                        if (P::QUEUE && T.batches >= 2048) { a.queue[8] = task_t0; a.queue[9] = wall_clock64(); a.queue[14] = n_champ_batches; }
+                        n_champ_batches = 0;
+#endif
 #if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: the task's number of batches in the upper half of the status word)
                         if (a.status) a.status[own_i * 8 + own_slot] = st | ((T.batches < 0x7fff ? T.batches : 0x7fff) << 16);
 #else
@@ -323,21 +370,80 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                     if (lane == 0) s_park = T;    // state after posting (batch counter, picked interval)
                 }
             }
-            if (finished) { have_task = false; continue; }
+            if (finished) {
+                if (champ_mine) {
+                    // give the title back (if it is still this task's): the other candidates enter again with their next batch
+                    if (lane == 0) {
+                        unsigned expect = champ_mine;
+                        __hip_atomic_compare_exchange_strong(flag_champ0 + 32u * title, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    champ_mine = 0;
+                    if (champion) __builtin_amdgcn_s_setprio(2);
+                    champion = false;
+                }
+                have_task = false;
+                continue;
+            }
             mask = wv_ballot(B.req_active);
 
-            // publish the batch when some wave is idle
-            unsigned idle = 0, act = 1;
+            // publish the batch when some wave is idle -- or, while the queue is still full, when this task holds the
+            // most batches of all tasks in flight (the squad serves it)
+            unsigned idle = 0, act = 1, exhausted = 0, champ_now = 0, title_next = title;
+            const unsigned cand = (early_on && !board_dead && task_batches >= a.early_min)
+                ? (((unsigned) (task_batches < 0xffff ? task_batches : 0xffff) << 16) | ((unsigned) blockIdx.x + 1u)) : 0u;
             if (lane == 0 && a.board) {
-                if (__hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                exhausted = __hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (exhausted) {
                     idle = __hip_atomic_load(flag_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (cand | champ_mine) {
+                    if (cand < champ_mine) {
+                        // the quadrature that competed for the title is over: give it back if it is still this task's
+                        unsigned expect = champ_mine;
+                        __hip_atomic_compare_exchange_strong(flag_champ0 + 32u * title, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (cand) {
+                        champ_now = __hip_atomic_load(flag_champ0 + 32u * title, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (champ_now > cand) {
+                            // a longer quadrature holds this title (this task's own entry, if any, is gone with it): compete
+                            // for the title whose holder is the shortest
+                            for (unsigned k = 0; k < a.early_classes; k++) {
+                                const unsigned v = __hip_atomic_load(flag_champ0 + 32u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (v < champ_now) { champ_now = v; title_next = k; }
+                            }
+                        }
+                        if (champ_now < cand) {
+                            const unsigned old = __hip_atomic_fetch_max(flag_champ0 + 32u * title_next, cand, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT);
+                            champ_now = old > cand ? old : cand;
+                        }
+                    }
                 }
             }
+            title = (unsigned) __builtin_amdgcn_readfirstlane((int) title_next);
             idle = (unsigned) __builtin_amdgcn_readfirstlane((int) idle);
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
+            exhausted = (unsigned) __builtin_amdgcn_readfirstlane((int) exhausted);
+            champ_now = (unsigned) __builtin_amdgcn_readfirstlane((int) champ_now);
+            if (early_on) {
+                champ_mine = cand;
+                const bool is_champ = cand != 0u && !exhausted && champ_now == cand;
+                if (is_champ != champion) { if (is_champ) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+                champion = is_champ;
+            }
             const int cnt = __builtin_popcountll(mask);
-            shared = idle != 0 && cnt >= 2 && !board_dead;
+            shared = (exhausted ? idle != 0 : champion) && cnt >= 2 && !board_dead;
+#if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when the longest outer quadrature passed 64 / 512 / 2048 subintervals, and how
+                               // many of its batches were published as the champion's)
+            if (P::QUEUE && lane == 0) {
+                if (task_batches == 64) atomicCAS(a.queue + 12, 0ull, wall_clock64());
+                if (task_batches == 512) atomicCAS(a.queue + 13, 0ull, wall_clock64());
+                if (task_batches == 2048) a.queue[2] = wall_clock64();
+            }
+            if (shared && !exhausted) n_champ_batches += 1;
+#endif
             if (shared) {
                 seq += 1;
                 src_seq = seq;
@@ -360,8 +466,9 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 drain_vmem();          // the claim word is out before anybody can see the hint
                 __syncthreads();
                 {
-                    const unsigned span = hint_span(act);
-                    const unsigned channel = ((unsigned) blockIdx.x + seq) & (span - 1u);
+                    // (while the queue is full the only listeners are the squad: every hint line of the title)
+                    const unsigned span = exhausted ? hint_span(act) : a.early_classes;
+                    const unsigned channel = exhausted ? (((unsigned) blockIdx.x + seq) & (span - 1u)) : title;
                     if (((unsigned) lane & (span - 1u)) == channel)
                         __hip_atomic_store(&hints[(unsigned) lane * BOARD_HINT_STRIDE], (seq << 16) | ((unsigned) blockIdx.x + 1u),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,12 +476,13 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             }
         } else {
             // ---------- helper: find a published batch through this wave's hint line ----------
-            unsigned h = 0, act = 1;
+            unsigned h = 0, act = 1, exh = 0;
             int leave = 0;
             unsigned long long c = 0;
             if (lane == 0) {
                 if ((n_polls & 15u) == 0) {
                     act = __hip_atomic_load(flag_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (squad && !seen_exhausted) exh = __hip_atomic_load(flag_exhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // More idle waves than the remaining owners can feed (a batch has <= 62 requests) only
                     // add polling traffic, which slows the waves that compute: the surplus leaves.
                     const unsigned keep = act * 64u + 32u;
@@ -399,10 +507,15 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             h = (unsigned) __builtin_amdgcn_readfirstlane((int) h);
             act = (unsigned) __builtin_amdgcn_readfirstlane((int) act);
             if (__builtin_amdgcn_readfirstlane(leave)) break;
+            if (squad && !seen_exhausted && __builtin_amdgcn_readfirstlane((int) exh)) {
+                seen_exhausted = true;
+                __builtin_amdgcn_s_setprio(0);
+            }
             n_polls += 1;
             COOP_DIAG(n_polls_total += 1;)
             if (h == 0) {
                 if (act == 0) break;       // every task is finished
+                if (squad && !seen_exhausted) idle_since = 0;      // the squad waits for a champion as long as the queue is full
                 // A wave that has seen nothing to do for 2 s leaves.  It holds no claim, so leaving is always safe,
                 // and it bounds every wait in this kernel: should part of the grid not be resident (the launch
                 // sizes it so that it is), the waves waiting for a slot get one instead of being waited for.
@@ -626,8 +739,28 @@ __global__ void board_init_kernel(unsigned *flags, unsigned active)
 // ------------------------------------------------------------------------------
 #define ORDER_BUCKETS 32
 
-__device__ __forceinline__ int order_bucket(double s, double theta, const double *gmin, const double *temp, size_t i)
+// The Faraday kernel's tasks have their own cost profile (per-coefficient batch counts of a -DRIM_TAIL_DIAG build, round 4,
+// all four tables): the fewer harmonics -- the smaller sigma0 = s sin(theta) -- the MORE batches (mean 37 at the top decile
+// of s, 67 at the bottom one; 200+ at sigma0 ~ 0.005), and the outer quadratures that run to GSL's limit of 4096
+// bisections (heyvaerts.rs:82-83; one task in ~1e5, thousands of sequential batches) all sat at sigma0 in [1.15, 2.4]
+// (power law: 2.15, 2.40; pitchy kappa: 1.15, 1.20, 1.41).  With the Symphony order (large s first) exactly these tasks
+// started last.  Here: the window 0.9 <= sigma0 <= 3 first (10 % of the rows; a chain that starts with the launch has
+// the whole launch to overlap with -- coop_common.h, early help), then ascending sigma0.
+__device__ __forceinline__ int faraday_order_bucket(double s, double theta)
 {
+    double sn, cs;
+    rim_sincos(theta, &sn, &cs);
+    const double sigma0 = s * rim_fabs(sn);
+    if (sigma0 >= 0.9 && sigma0 <= 3.) return 0;
+    if (!(sigma0 > 0.)) return ORDER_BUCKETS - 1;
+    const int e = (int) ((rim_bits(sigma0) >> 52) & 0x7ff) - 1023;     // floor(log2 sigma0) for normal sigma0
+    const int b = e + 11;                                                // sigma0 < 2^-10 -> 1, ..., sigma0 >= 2^19 -> 31
+    return b < 1 ? 1 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
+}
+
+__device__ __forceinline__ int order_bucket(double s, double theta, const double *gmin, const double *temp, size_t i, int faraday)
+{
+    if (faraday) return faraday_order_bucket(s, theta);
     // Thermal distribution: the long tasks are the COLD, LOW-FREQUENCY, SMALL-ANGLE points, not the large-s ones -- there
     // j_V / alpha_V march through ~300 batches of the tail integral before GSL's round-off detector ends them (NaN, as in
     // the reference), ten times the table's median.  Measured on 65536 rows of configs[2]'s table with the per-coefficient
@@ -663,10 +796,11 @@ __device__ __forceinline__ int order_bucket(double s, double theta, const double
     return b < 1 ? 1 : (b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b);
 }
 
-__global__ void order_hist_kernel(const double *s, const double *theta, const double *gmin, const double *temp, size_t n, unsigned *hist)
+__global__ void order_hist_kernel(const double *s, const double *theta, const double *gmin, const double *temp, size_t n, unsigned *hist,
+                                  int faraday)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[order_bucket(s[i], theta[i], gmin, temp, i)], 1u);
+    if (i < n) atomicAdd(&hist[order_bucket(s[i], theta[i], gmin, temp, i, faraday)], 1u);
 }
 
 __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, one thread
@@ -678,10 +812,10 @@ __global__ void order_scan_kernel(unsigned *hist)   // exclusive scan in place, 
 }
 
 __global__ void order_scatter_kernel(const double *s, const double *theta, const double *gmin, const double *temp, size_t n,
-                                     unsigned *offsets, unsigned *perm)
+                                     unsigned *offsets, unsigned *perm, int faraday)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i], theta[i], gmin, temp, i)], 1u)] = (unsigned) i;
+    if (i < n) perm[atomicAdd(&offsets[order_bucket(s[i], theta[i], gmin, temp, i, faraday)], 1u)] = (unsigned) i;
 }
 
 // fills the slots that were not selected (or not yet available) with NaN
@@ -841,6 +975,9 @@ struct rimphony_ctx {
     int resident_group[2][4];       // [Symphony groups / Faraday pair][kind]
     int f32_variant;                // RIMPHONY_F32_VARIANT=1: accept RIMPHONY_PRECISION_F32_INTEGRAND (measurement hook)
     int sym_solo;                   // RIMPHONY_SYM_SOLO=1: one wave per (point, coefficient), the round-2 kernel (A/B measurements)
+    int faraday_symphony_order;     // RIMPHONY_FARADAY_ORDER=symphony: the Faraday launch visits the points in the Symphony order (A/B measurements)
+    int early_squad;                // RIMPHONY_EARLY_SQUAD: waves of the Faraday grid that serve the longest chain from the start (0: off; -1: the kind's default)
+    int early_min;                  // RIMPHONY_EARLY_MIN: batches after which a task competes for that help
     int faraday_group;              // RIMPHONY_FARADAY_GROUP=1: rho_Q and rho_V of a point in lock-step (measured slower: DESIGN.md section 5)
 };
 
@@ -950,6 +1087,9 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     if (!c->mu) { delete c; return RIMPHONY_ENOMEM; }
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
+    { const char *e = getenv("RIMPHONY_FARADAY_ORDER"); c->faraday_symphony_order = (e && e[0] == 's'); }
+    { const char *e = getenv("RIMPHONY_EARLY_SQUAD"); c->early_squad = e ? atoi(e) : -1; if (c->early_squad > 1024) c->early_squad = 1024; }
+    { const char *e = getenv("RIMPHONY_EARLY_MIN"); c->early_min = e ? atoi(e) : 16; if (c->early_min < 1) c->early_min = 1; }
     { const char *e = getenv("RIMPHONY_F32_VARIANT"); c->f32_variant = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_FARADAY_GROUP"); c->faraday_group = (e && e[0] == '1'); }
     c->shared_mode = take_device_lock(device, &c->lock_fd);
@@ -1144,9 +1284,25 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     b.board_flags = (unsigned *) (c->d_board + c->board_slots);
     b.idle_ticks = 2ull * c->ticks_per_s;
     b.owner_ticks = c->owner_wait_ticks;
-    // every claim word starts closed (count 0); flags: not exhausted, `grid` active waves, nobody idle
+    // the squad that serves the longest chain from the start (coop_common.h): only where there is a bulk to overlap
+    // with (many more tasks than waves) and the GPU is this context's own; blocks k * stride with an odd stride, so
+    // that the squad is spread over the XCDs (blocks go to them round-robin) and their CUs
+    b.early_squad = 0;
+    b.early_stride = 1;
+    b.early_classes = 1;
+    b.early_min = c->early_min;
+    const unsigned want_squad = c->early_squad >= 0 ? (unsigned) c->early_squad : (unsigned) P::EARLY_SQUAD;
+    if (P::EARLY_HELP && b.board && !c->shared_mode && want_squad && ntasks >= 4ull * grid && grid >= 16u * want_squad) {
+        b.early_stride = (grid / want_squad) | 1u;
+        const unsigned fit = (grid - 1u) / b.early_stride + 1u;
+        b.early_squad = want_squad < fit ? want_squad : fit;
+        // one title per 64 waves of the squad (a batch has up to 62 requests), at most four
+        b.early_classes = b.early_squad >= 256u ? 4u : b.early_squad >= 128u ? 2u : 1u;
+    }
+    // every claim word starts closed (count 0); flags: not exhausted, `grid` waves that may fetch a task (the squad
+    // never does), nobody idle
     HIP_TRY(hipMemsetAsync(c->d_board, 0, (size_t) grid * sizeof(AssistSlot), st));
-    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid);
+    hipLaunchKernelGGL(board_init_kernel, dim3(1), dim3(128), RIM_DYN_LDS, st, b.board_flags, grid - b.early_squad);
     HIP_TRY(hipEventRecord(ev_start, st));
     hipLaunchKernelGGL(coop_kernel<P>, dim3(grid), dim3(64), RIM_DYN_LDS, st, b);
     HIP_TRY(hipGetLastError());
@@ -1346,16 +1502,25 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
     a.spill = nullptr;
     a.board = nullptr;
     a.board_flags = nullptr;
-    if (n > 4096 && n < 0xffffffffull) {
+    const bool ordered = n > 4096 && n < 0xffffffffull;
+    const double *const order_gmin = (kind == RIMPHONY_POWER_LAW) ? pp.p[1] : (kind == RIMPHONY_PITCHY_PL) ? pp.p[2] : nullptr;
+    const double *const order_temp = (kind == RIMPHONY_THERMAL_JUETTNER) ? pp.p[0] : nullptr;
+    // the visiting order of the Symphony launch now; the Faraday launch gets its own (same array, rebuilt on the stream
+    // after the Symphony kernel: see below)
+    auto build_order = [&](int faraday) -> int {
         unsigned *hist = c->d_perm + c->norm_cap;
         const unsigned nb = (unsigned) ((n + 255) / 256);
         HIP_TRY(hipMemsetAsync(hist, 0, ORDER_BUCKETS * sizeof(unsigned), st));
-        const double *gmin = (kind == RIMPHONY_POWER_LAW) ? pp.p[1] : (kind == RIMPHONY_PITCHY_PL) ? pp.p[2] : nullptr;
-        const double *temp = (kind == RIMPHONY_THERMAL_JUETTNER) ? pp.p[0] : nullptr;
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, temp, n, hist);
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, order_gmin, order_temp, n, hist, faraday);
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), RIM_DYN_LDS, st, hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, gmin, temp, n, hist, c->d_perm);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), RIM_DYN_LDS, st, d_s, d_theta, order_gmin, order_temp, n, hist,
+                           c->d_perm, faraday);
         HIP_TRY(hipGetLastError());
+        return RIMPHONY_OK;
+    };
+    if (ordered) {
+        rc = build_order(0);
+        if (rc) return rc;
         a.perm = c->d_perm;
     }
     a.heartbeat = c->hb_dev;
@@ -1363,6 +1528,10 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
     a.work = (unsigned long long *) d_work;
     a.idle_ticks = 0;
     a.owner_ticks = 0;
+    a.early_squad = 0;          // (set per launch by launch_coop)
+    a.early_stride = 1;
+    a.early_classes = 1;
+    a.early_min = 0;
     if (d_work) HIP_TRY(hipMemsetAsync(d_work, 0, n * 8 * sizeof(uint64_t), st));
     a.nslots = 0;
     uint32_t computed = 0;
@@ -1403,6 +1572,10 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
             default: rc = launch_symphony<3>(c, a, st); break;
             }
         }
+        if (rc) return rc;
+    }
+    if (fa.nslots > 0 && ordered && !c->faraday_symphony_order) {
+        rc = build_order(1);
         if (rc) return rc;
     }
     if (fa.nslots > 0 && c->faraday_group) {

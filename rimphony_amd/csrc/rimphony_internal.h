@@ -34,6 +34,13 @@
                                  // pitchy-kappa points, whose tail is sequential -- 5 kept)
 #endif
 
+// waves of the Faraday kernel's grid that serve the launch's longest outer quadrature from the start (coop_common.h,
+// SymArgs::early_squad), for the kinds that have such chains (HeyvaertsProblem::EARLY_SQUAD); RIMPHONY_EARLY_SQUAD
+// overrides for every kind, 0 = off
+#ifndef RIM_EARLY_SQUAD_DEFAULT
+#define RIM_EARLY_SQUAD_DEFAULT 64
+#endif
+
 #if defined(RIM_PROF)
 #define RIM_DYN_LDS 256             // the region timers accumulate in dynamic LDS
 #else

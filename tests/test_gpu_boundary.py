@@ -335,6 +335,38 @@ def test_f32_integrand_is_refused_and_slower_where_it_still_runs(gpu_ctx):
     assert same_bits(a[:, 6:], b[:, 6:]).all()              # the Faraday pair is not part of the variant: fp64 bits
 
 
+def test_early_help_and_faraday_order_change_no_bit(gpu_ctx):
+    """The Faraday launch's scheduling knobs (round 4): its own visiting order (the window 0.9 <= s sin(theta) <= 3 first,
+    then ascending; RIMPHONY_FARADAY_ORDER=symphony restores the shared one) and the squad that serves the longest outer
+    quadratures from the start of a launch (coop_common.h; RIMPHONY_EARLY_SQUAD = 0 / 64 / 256: off, one title, four
+    titles).  Who evaluates a request, and when, never changes its value: the same 12288 power-law and pitchy-kappa rows
+    (enough tasks for the squad to be switched on: four per wave of the grid) give the same table and status words, bit
+    for bit, under every setting.  Each leg on a context that owns the device."""
+    from rimphony_amd import api
+    for cfg in ("cfg2_powerlaw_8", "cfg5_pitchykappa_8"):
+        kind, _, s, th, params = workload.make_batch(cfg, 12288, start=1131072 if cfg == "cfg2_powerlaw_8" else 0)
+        ref = None
+        for env in ({"RIMPHONY_EARLY_SQUAD": "0", "RIMPHONY_FARADAY_ORDER": "symphony"}, {"RIMPHONY_EARLY_SQUAD": "0"},
+                    {"RIMPHONY_EARLY_SQUAD": "64", "RIMPHONY_EARLY_MIN": "4"}, {"RIMPHONY_EARLY_SQUAD": "256", "RIMPHONY_EARLY_MIN": "4"}, {}):
+            with gpu_ctx.released():
+                os.environ.update(env)
+                try:
+                    ctx = api.Context(0)
+                finally:
+                    for k in env:
+                        del os.environ[k]
+                try:
+                    assert not ctx.shared_mode()
+                    out, st = ctx.compute_batch(kind, s, th, params, 0xC0, want_status=True)
+                finally:
+                    ctx.close()
+            if ref is None:
+                ref = (out, st)
+            else:
+                assert same_bits(out[:, 6:], ref[0][:, 6:]).all(), (cfg, env)
+                assert (st[:, 6:] == ref[1][:, 6:]).all(), (cfg, env)
+
+
 def test_kernel_variants_change_no_bit(gpu_ctx):
     """The A/B switches of the library: RIMPHONY_SYM_SOLO=1 (one wave per (point, coefficient), the round-2 Symphony
     kernel) and RIMPHONY_FARADAY_GROUP=1 (rho_Q and rho_V of a point in lock-step, heyvaerts_group.h -- measured slower,
