@@ -223,7 +223,10 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
         unsigned serve = 0;             // members whose rule sums this turn's pass produces
         unsigned booknow = 0;           // ... of them, those that picked the pass's interval: booked from the registers
         unsigned from_stash = 0;        // members whose pick is on file: booked without a pass
-        int idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0;      // entry of the pass's interval in each served member's list
+        // entry of the pass's interval in each served member's list: four 16-bit fields of one wave-uniform word (list
+        // indices stay below the GSL limits, 5000 / 4096) -- as four ints indexed by the member they lived in a scratch
+        // array and came back as vector registers
+        unsigned long long idxp = 0;
         double a_i = 0., b_i = 0.;      // the pass's interval (uniform)
         double la = 0., lb = 0.;        // per lane: the interval this lane's sample belongs to
         bool active_lane = false, second = false;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     if (imax < st.cap) { a_i = st.a[imax]; b_i = st.b[imax]; }
                     else { a_i = st.g[imax - st.cap]; b_i = st.g[st.gcap + (imax - st.cap)]; }
                     a_i = uni(a_i); b_i = uni(b_i);
-                    idx0 = idx1 = idx2 = idx3 = imax;
+                    idxp = (unsigned long long) (unsigned) imax * 0x0001000100010001ull;
                 }
                 const unsigned long long abits = rim_bits(a_i), bbits = rim_bits(b_i);
                 serve = booknow = 1u << m0;
@@ -289,7 +292,10 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                             if (((stashed >> m) & 1u) && stash_find(M, idx, lane) >= 0) idx = -1;       // already on file
                         }
                     }
-                    if (idx >= 0) { serve |= 1u << m; put4(m, idx, idx0, idx1, idx2, idx3); }
+                    if (idx >= 0) {
+                        serve |= 1u << m;
+                        idxp = (idxp & ~(0xffffull << (16 * m))) | ((unsigned long long) (unsigned) idx << (16 * m));
+                    }
                 }
                 const double mid = 0.5 * (a_i + b_i);
                 la = g.half ? mid : a_i;
@@ -340,8 +346,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     if ((booknow >> m) & 1u) {
                         RIM_PROF_T(t_ab);
                         const IStore st = group_store(inner_lds, CAP_GINNER, inner_spill, SPILL_GINNER, m);
-                        // (the entry indices are wave-uniform but come back from scratch as vector registers: say so)
-                        const bool fin = group_book(M, st, g, cur, uni(sel4(m, idx0, idx1, idx2, idx3)), a_i, b_i,
+                        const bool fin = group_book(M, st, g, cur, (int) ((idxp >> (16 * m)) & 0xffffull), a_i, b_i,
                                                     r.result, r.abserr, readlane_d(r.result, 32), readlane_d(r.abserr, 32),
                                                     (ne & 1ull) && ((ne >> 32) & 1ull), r.result, r.abserr, epsrel, limit);
                         n_samp_all += 62u;
@@ -351,7 +356,7 @@ __device__ __forceinline__ void wave_qag_group(F &f, const GKLane &g, double *in
                     } else {
                         // file the children's sums in the member's stash (a free place, else the next one in turn)
                         RIM_PROF_T(t_file);
-                        const int idx = uni(sel4(m, idx0, idx1, idx2, idx3));
+                        const int idx = (int) ((idxp >> (16 * m)) & 0xffffull);
                         const unsigned long long freep = wv_ballot(lane < RIM_STASH && M->sk[lane & (RIM_STASH - 1)] < 0);
                         const int pos = freep ? __builtin_ffsll((long long) freep) - 1 : uni(M->snext);
                         wv_sync();
