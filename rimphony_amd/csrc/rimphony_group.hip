@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
 
         // ---------- evaluate entries of `src` (the integrand lives here, once) ----------
         double gv0 = 0., gv1 = 0., gv2 = 0., gv3 = 0.;
-        int bs0 = 0, bs1 = 0, bs2 = 0, bs3 = 0;
+        unsigned bsp = 0;                   // status bits of each member's batch, 8 bits per member (wave-uniform)
         bool ctx_loaded = !helper;
         int got = 0;
         size_t work_i = own_i;
@@ -452,6 +452,9 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 }
                 if (ek0 < 0) break;
             }
+            // (wave-uniform by construction -- readlane / readfirstlane results merged over the two paths above; saying so
+            // keeps the member loops below on the scalar unit)
+            mk0 = uni(mk0); mk1 = uni(mk1); ek0 = uni(ek0); ek1 = uni(ek1);
             got += 1;
             RIM_PROF_T(t_req);
             P::eval(cx, slots, g, s_ginner, inner_spill, &s_gp, n0, lb0, mk0, n1, lb1, mk1);
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                         const int m = __builtin_ctz(rem);
                         int st = 0;
                         const double v = group_entry_value(&s_gp, m, e, st);
-                        put4(m, sel4(m, bs0, bs1, bs2, bs3) | st, bs0, bs1, bs2, bs3);
+                        bsp |= (unsigned) (st & 0xff) << (8 * m);
                         if (lane == ek) put4(m, v, gv0, gv1, gv2, gv3);
                     }
                 }
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                     int bst = 0;
                     if (wv_ballot((stl & ST_INNER_FAIL) != 0)) bst |= ST_INNER_FAIL;
                     if (wv_ballot((stl & ST_STORE_FULL) != 0)) bst |= ST_STORE_FULL;
-                    put4(mm, bst, bs0, bs1, bs2, bs3);
+                    bsp = (bsp & ~(0xffu << (8 * mm))) | ((unsigned) bst << (8 * mm));
                 }
             } else {
                 // a claimed entry has not come back within the bound: the owner closes the round, evaluates ALL of it
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
                 board_dead = true;
                 shared = false;
                 gv0 = gv1 = gv2 = gv3 = 0.;
-                bs0 = bs1 = bs2 = bs3 = 0;
+                bsp = 0;
                 redo = true;
             }
         }
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(64, P::WAVES) void group_kernel(GroupArgs ga)
             B.req_active = ((act >> m) & 1u) != 0;
             B.n_req = sel4(m, nq0, nq1, nq2, nq3);
             B.phase = sel4(m, ph0, ph1, ph2, ph3);
-            P::consume(cx, group_slot(own_slots, m), g, outer, T, B, sel4(m, gv0, gv1, gv2, gv3), uni(sel4(m, bs0, bs1, bs2, bs3)));
+            P::consume(cx, group_slot(own_slots, m), g, outer, T, B, sel4(m, gv0, gv1, gv2, gv3), (int) ((uni(bsp) >> (8 * m)) & 0xffu));
             __syncthreads();
             if (lane == 0) s_park[m] = T;
             if (P::done(T)) alive &= ~(1u << m);
