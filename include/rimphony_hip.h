@@ -115,6 +115,11 @@ typedef struct rimphony_ctx rimphony_ctx;
  * RIMPHONY_SYM_SOLO=1 runs the six Symphony coefficients one wave per (point, coefficient) as until round 2 instead of
  * the coefficients of a point in lock-step; RIMPHONY_FARADAY_GROUP=1 runs rho_Q and rho_V of a point in lock-step as well
  * (measured slower than one wave per coefficient, hence off).  Both for A/B measurements: the tables do not change.
+ * RIMPHONY_EARLY_SQUAD=<n> sets how many waves of the Faraday kernel's grid serve the longest outer quadratures of a
+ * launch from its first cycle instead of fetching tasks (0: none; default 64 for the power-law family, 256 for pitchy kappa,
+ * 0 for the other two distributions; only on launches with at least four tasks per wave, never in shared mode),
+ * RIMPHONY_EARLY_MIN=<n> the size from which an outer quadrature competes for them (16), RIMPHONY_FARADAY_ORDER=symphony
+ * makes the Faraday launch visit the points in the Symphony launch's order.  Scheduling only: the tables do not change.
  * RIMPHONY_OWNER_WAIT_US=<n> (test hook) shortens the 120 s an owner wave waits for its helpers before it recomputes
  * a published batch itself; results do not depend on it. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);
