@@ -67,6 +67,7 @@ struct SymArgs {
     // holds the title for a few batches at most (the squad serves it and it is soon over); the one that is on its way to
     // GSL's limit outgrows every other, keeps the title and advances at the pace of the cooperative tail (~0.25 ms a
     // batch) alongside the bulk instead of after it.  Who evaluates a request never changes its value: tables are bit-identical.
+    int turbo;                  // rounds of the long outer quadratures (heyvaerts_wave.h; RIMPHONY_ROUNDS=0 turns them off)
     unsigned early_squad, early_stride;
     unsigned early_classes;     // 1, 2 or 4 titles (64 waves of the squad each): that many long quadratures are served side by side
     int early_min;
@@ -103,16 +104,20 @@ __constant__ int c_slot_stokes[8] = { 0, 0, 1, 1, 2, 2, 1, 2 };
 // polls stay spread over 64 lines.  (All waves polling the same few lines -- and a per-poll look at
 // the claim word -- was measured to slow the computing waves several-fold.)
 // Idle waves count themselves in flags[IDLE] so that owners publish only when somebody can help.
+// A batch normally has up to 62 requests (the Kronrod nodes of an interval's two children).  A long outer quadrature of
+// the Faraday kernel publishes the children of up to RIM_TURBO_MAX intervals in one batch (heyvaerts_wave.h, "rounds"):
+// 62 requests per interval, 248 in all -- the count and cursor fields of the claim word are 8 bits wide.
+#define RIM_SLOT_REQS 256           // >= 62 * RIM_TURBO_MAX (symphony_wave.h)
 struct AssistSlot {
     unsigned long long claim;
     unsigned long long point;
     unsigned done;
     int slot;
-    unsigned long long req_n[64];     // bit patterns of doubles: every access is an agent-scope atomic
-    unsigned long long res[64];
-    int req_lobe[64];
-    int res_status[64];
-    unsigned res_samples[64];         // integrand samples the request took (booked by the owner when it reads the value)
+    unsigned long long req_n[RIM_SLOT_REQS];     // bit patterns of doubles: every access is an agent-scope atomic
+    unsigned long long res[RIM_SLOT_REQS];
+    int req_lobe[RIM_SLOT_REQS];
+    int res_status[RIM_SLOT_REQS];
+    unsigned res_samples[RIM_SLOT_REQS];         // integrand samples the request took (booked by the owner when it reads the value)
 };
 
 // Board payload accessors: relaxed agent-scope atomics = sc1 (write-through / L1-bypassing) stores

@@ -20,7 +20,8 @@ namespace rim {
 #define RIM_HEY_MAX_STEPS 4096
 
 enum HeyStage { HS_NR_FIRST = 0, HS_NR_RIGHT, HS_NR_LEFT, HS_QR, HS_DONE };
-enum HeyPhase { HP_DERIV1 = 0, HP_DERIV2, HP_QAG_FIRST, HP_QAG_BISECT };
+enum HeyPhase { HP_DERIV1 = 0, HP_DERIV2, HP_QAG_FIRST, HP_QAG_BISECT,
+                HP_QAG_STASHED };   // (batch phase only) a bisection whose children's rule sums were on file: no requests
 
 struct HeyTask {
     double nr_val, qr_val;
@@ -43,6 +44,39 @@ __device__ __forceinline__ void hey_uniformize(HeyTask &T)
     T.stage = uni(T.stage); T.phase = uni(T.phase); T.steps = uni(T.steps); T.status = uni(T.status);
     T.batches = uni(T.batches); T.failed = uni(T.failed);
     qag_uniformize(T.oq);
+}
+
+// ---- rounds: the long outer quadratures, several bisections per batch -----------------------------------------
+// An outer quadrature that does not converge works through its list breadth first: measured with the oracle on the
+// three 4096-subinterval quadratures of the bench tables (profiles/r4_outer_pick_statistics.txt), the interval qag.c picks
+// next is a child of the one just bisected in 1-2 % of the steps.  The rule sums of an interval's children are a function
+// of the interval alone, so they can be computed BEFORE qag.c asks for them: when the picked interval's sums are not on
+// file, the batch carries -- besides its two children -- the children of the next RIM_TURBO_MAX - 1 intervals in qag.c's
+// own order (descending error, stamp), and their sums are filed in the wave's HeyStash; a later pick that finds its sums
+// there is booked without a batch.  qag.c's sequence of picks, sums, round-off counters and decisions is untouched (the
+// mechanism of symphony_group.h's stash, one level up); a filed entry that is never picked -- the quadrature ended --
+// is dropped together with its status bits and sample counts, so values, status words and work counters do not depend on
+// whether rounds were used.  3.9 bisections per batch on those quadratures: the chain of sequential batches that bounds
+// the end of a launch is that much shorter.
+#define RIM_HEY_STASH 8
+#define RIM_ROUND_MIN_SIZE 48
+struct HeyStash {
+    double a[RIM_HEY_STASH], b[RIM_HEY_STASH];          // the interval (bit patterns compared); used bit in `used`
+    double v[RIM_HEY_STASH][6];                         // area1, error1, resasc1, area2, error2, resasc2 (lane 0's view)
+    int status[RIM_HEY_STASH];                          // status bits of the entry's 62 inner integrals
+    unsigned long long samples[RIM_HEY_STASH];          // their integrand samples (work counters)
+    unsigned used;
+    // the batch in flight: the intervals besides the picked one whose children it evaluates (round_n = 1 + their number),
+    // and the place of the picked interval's sums in the stash when they were on file (-1: not)
+    int round_n, hit;
+    double ra[RIM_TURBO_MAX - 1], rb[RIM_TURBO_MAX - 1];
+};
+__device__ __forceinline__ int hey_stash_find(const HeyStash *hs, double a, double b, int lane)
+{
+    const int k = lane & (RIM_HEY_STASH - 1);
+    const unsigned long long hit = wv_ballot(lane < RIM_HEY_STASH && ((uni(hs->used) >> k) & 1u) &&
+                                             rim_bits(hs->a[k]) == rim_bits(a) && rim_bits(hs->b[k]) == rim_bits(b));
+    return hit ? __builtin_ffsll((long long) hit) - 1 : -1;
 }
 
 // ---- the coefficient as a resumable computation (same shape as symphony_wave.h) -----------
@@ -106,11 +140,55 @@ __device__ __forceinline__ void hey_begin(const HeyPoint &pt, HeyTask &T)
     qag_begin(T.oq, 0., 1e-3, 4096);
 }
 
+// The next `want` intervals of the outer list in qag.c's order after the picked one -- descending (error, stamp), the
+// order of its sorted list -- that are not on file already: hs->ra / rb, hs->round_n = 1 + their number.
+__device__ __forceinline__ void hey_round_select(const IStore &outer, const HeyTask &T, HeyStash *hs, int want, int lane)
+{
+    double pe = T.oq.e_i;                       // the picked interval: the largest (error, stamp)
+    int pstamp = uni(ist_stamp(outer, T.oq.imax));
+    int n = 1;
+    for (int tries = 0; tries < want + RIM_HEY_STASH && n - 1 < want; tries++) {
+        // wave-wide argmax over the entries strictly below (pe, pstamp)
+        double be = -1.0;
+        int bs = -1, bi = -1;
+        for (int i = lane; i < T.oq.size; i += 64) {
+            const double e = ist_e(outer, i);
+            const int s = ist_stamp(outer, i);
+            const bool below = e < pe || (e == pe && s < pstamp);
+            if (below && (e > be || (e == be && s > bs))) { be = e; bs = s; bi = i; }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const double oe = wv_shfl_xor(be, m);
+            const int os = wv_shfl_xor(bs, m);
+            const int oi = wv_shfl_xor(bi, m);
+            if (oe > be || (oe == be && os > bs)) { be = oe; bs = os; bi = oi; }
+        }
+        const int idx = wv_readfirstlane(bi);
+        if (idx < 0) break;                     // the list has no further entry
+        pe = uni(be); pstamp = wv_readfirstlane(bs);
+        const double a = uni(ist_a(outer, idx)), b = uni(ist_b(outer, idx));
+        if (hey_stash_find(hs, a, b, lane) >= 0) continue;      // its children's sums are on file
+        if (lane == 0) { hs->ra[n - 1] = a; hs->rb[n - 1] = b; }
+        n++;
+    }
+    if (lane == 0) hs->round_n = n;
+    wv_sync();
+}
+
 // Post the next batch.  Returns false (and ends the task) when the batch backstop is hit.
-__device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, const IStore &outer, HeyTask &T, SymBatch &B)
+// hs / rounds: the wave's stash and how many further intervals this batch may evaluate besides the picked one (0: none,
+// and hs may be null) -- the Faraday kernel's long outer quadratures, see HeyStash above.
+__device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, const IStore &outer, HeyTask &T, SymBatch &B,
+                                         HeyStash *hs = nullptr, int rounds = 0)
 {
     const int lane = g.lane;
     B.req_n = 0.; B.req_lobe = T.stage == HS_QR ? 1 : 0; B.req_active = false; B.n_req = 0; B.phase = T.phase;
+    if (hs && (uni(hs->round_n) != 1 || uni(hs->hit) >= 0)) {       // whatever the previous batch was: this one starts plain
+        wv_sync();
+        if (lane == 0) { hs->round_n = 1; hs->hit = -1; }
+        wv_sync();
+    }
     if (++T.batches > RIM_MAX_BATCHES) { T.status |= ST_CHUNK_CAP; hey_fail(T); return false; }
     if (T.phase == HP_DERIV1 || T.phase == HP_DERIV2) {
         B.n_req = 4;
@@ -126,15 +204,59 @@ __device__ __forceinline__ bool hey_post(const HeyPoint &pt, const GKLane &g, co
         B.req_active = g.node && g.half == 0;
     } else {
         qag_pick(T.oq, outer, lane);
+        if (hs) {
+            const int hit = uni(hs->used) ? hey_stash_find(hs, T.oq.a1, T.oq.b2, lane) : -1;
+            if (hit >= 0) {                                               // booked without a batch
+                wv_sync();
+                if (lane == 0) hs->hit = hit;
+                wv_sync();
+                B.phase = HP_QAG_STASHED;
+                return true;
+            }
+        }
         const double la = g.half ? T.oq.a2 : T.oq.a1;
         const double lb = g.half ? T.oq.b2 : T.oq.b1;
         const double center = 0.5 * (la + lb);
         const double hl = 0.5 * (lb - la);
         B.req_n = center + hl * gk_t(g);
         B.req_active = g.node;
+        // (only a quadrature that has grown past RIM_ROUND_MIN_SIZE subintervals: one that converges would leave the
+        // further intervals' sums unused)
+        if (hs && rounds > 0 && T.oq.size >= RIM_ROUND_MIN_SIZE) {
+            const int room = RIM_HEY_STASH - __builtin_popcount(uni(hs->used));
+            const int want = rounds < room ? rounds : room;
+            if (want > 0) hey_round_select(outer, T, hs, want, lane);
+        }
     }
     return true;
 }
+
+// The abscissa of the lane's request for further interval j (1 <= j < round_n) of a round: the same expression as
+// hey_post's for the picked interval.
+__device__ __forceinline__ double hey_round_request(const HeyStash *hs, const GKLane &g, int j)
+{
+    const double a = hs->ra[j - 1], b = hs->rb[j - 1];
+    const double mid = 0.5 * (a + b);
+    const double la = g.half ? mid : a;
+    const double lb = g.half ? b : mid;
+    const double center = 0.5 * (la + lb);
+    const double hl = 0.5 * (lb - la);
+    return center + hl * gk_t(g);
+}
+
+// Where the results of a round's further intervals are read from (the owner's board slot): request `rank` of further
+// interval j sits at per * j + rank.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIM_WAVE_EMU)
+#define HEY_IO_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define HEY_IO_LOAD(p) (*(p))
+#endif
+struct HeyRoundIO {
+    const unsigned long long *res;
+    const int *res_status;
+    const unsigned *res_samples;
+    int rank, per;
+};
 
 // One or two requests: the inner integral at outer abscissa u (heyvaerts.rs:213-250 non-resonant, 262-296
 // quasi-resonant).  THE site of the inner QAG and the integrand.  Two requests share their first rule
@@ -212,8 +334,13 @@ __device__ __forceinline__ double hey_eval_request(const HeyPoint &pt, const Dis
 }
 
 // Continuation of the phase that posted B (lane k holds the value of request k).
+// hs: the wave's stash (rounds; null: none).  stash_samples: out, the integrand samples of a bisection that was booked
+// from the stash (they count for the coefficient when its sums are consumed); dropped_samples: out, += the samples of
+// filed sums that the end of the quadrature left unused.
 __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g, const IStore &outer, HeyTask &T,
-                                            const SymBatch &B, double gval, int batch_status)
+                                            const SymBatch &B, double gval, int batch_status, HeyStash *hs = nullptr,
+                                            unsigned long long *stash_samples = nullptr, unsigned long long *dropped_samples = nullptr,
+                                            const HeyRoundIO *io = nullptr)
 {
     const int lane = g.lane;
     const int phase = B.phase;
@@ -274,15 +401,103 @@ __device__ __forceinline__ void hey_consume(const HeyPoint &pt, const GKLane &g,
         chunk_done = qag_after_first(T.oq, outer, lane, T.qa, T.qb, readlane_d(r.result, 0), readlane_d(r.abserr, 0),
                                      readlane_d(r.resabs, 0), readlane_d(r.resasc, 0));
     } else {
-        const double la = g.half ? T.oq.a2 : T.oq.a1;
-        const double lb = g.half ? T.oq.b2 : T.oq.b1;
-        const double hl = 0.5 * (lb - la);
-        const GKRes r = wave_gk31(gval, hl, g);
-        chunk_done = qag_after_bisect(T.oq, outer, lane,
-                                      readlane_d(r.result, 0), readlane_d(r.abserr, 0), readlane_d(r.resasc, 0),
-                                      readlane_d(r.result, 32), readlane_d(r.abserr, 32), readlane_d(r.resasc, 32));
+        // A bisection.  The children's rule sums of the picked interval come from this batch's values -- or from the
+        // stash, when an earlier round evaluated them (HP_QAG_STASHED) -- and go to qag.c's loop body; a round's
+        // further intervals (j >= 1: values from the board) get the same arithmetic and go to the stash.  One site of
+        // the rule sums and one of the loop body for all of them.
+        const bool stashed = phase == HP_QAG_STASHED;
+        const int nr = (hs && io && !stashed) ? uni(hs->round_n) : 1;
+        chunk_done = false;
+        unsigned long long unused = 0;          // per lane: samples of further intervals that nobody will ask for
+        for (int j = 0; j < nr; j++) {
+            double a = T.oq.a1, b = T.oq.b2, gv = gval;
+            int stl = 0;
+            unsigned smp = 0;
+            if (j > 0) {
+                a = uni(hs->ra[j - 1]); b = uni(hs->rb[j - 1]);
+                gv = 0.;
+                if (g.node) {
+                    gv = rim_frombits(HEY_IO_LOAD(&io->res[io->per * j + io->rank]));
+                    stl = HEY_IO_LOAD(&io->res_status[io->per * j + io->rank]);
+                    smp = HEY_IO_LOAD(&io->res_samples[io->per * j + io->rank]);
+                }
+                if (chunk_done) { unused += smp; continue; }      // the quadrature ended with the picked interval
+            }
+            double a1, e1, s1, a2, e2, s2;
+            if (stashed) {
+                const int k = uni(hs->hit);
+                a1 = uni(hs->v[k][0]); e1 = uni(hs->v[k][1]); s1 = uni(hs->v[k][2]);
+                a2 = uni(hs->v[k][3]); e2 = uni(hs->v[k][4]); s2 = uni(hs->v[k][5]);
+                T.status |= uni(hs->status[k]);
+                if (stash_samples) {
+                    const unsigned long long sm = hs->samples[k];
+                    *stash_samples = ((unsigned long long) (unsigned) wv_readfirstlane((int) (unsigned) (sm >> 32)) << 32) |
+                                     (unsigned) wv_readfirstlane((int) (unsigned) sm);
+                }
+                const unsigned used = uni(hs->used);
+                wv_sync();
+                if (lane == 0) hs->used = used & ~(1u << k);
+                wv_sync();
+            } else {
+                const double mid = 0.5 * (a + b);
+                const double la = g.half ? mid : a;
+                const double lb = g.half ? b : mid;
+                const double hl = 0.5 * (lb - la);
+                const GKRes r = wave_gk31(gv, hl, g);
+                a1 = readlane_d(r.result, 0); e1 = readlane_d(r.abserr, 0); s1 = readlane_d(r.resasc, 0);
+                a2 = readlane_d(r.result, 32); e2 = readlane_d(r.abserr, 32); s2 = readlane_d(r.resasc, 32);
+            }
+            if (j == 0) {
+                chunk_done = qag_after_bisect(T.oq, outer, lane, a1, e1, s1, a2, e2, s2);
+                continue;
+            }
+            // file the further interval's sums, with the status bits and the sample count of its 62 inner integrals
+            int st = 0;
+            if (wv_ballot((stl & ST_INNER_FAIL) != 0)) st |= ST_INNER_FAIL;
+            if (wv_ballot((stl & ST_STORE_FULL) != 0)) st |= ST_STORE_FULL;
+            unsigned long long tot = smp;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const unsigned lo = (unsigned) wv_shfl_xor((int) (unsigned) tot, m), hi = (unsigned) wv_shfl_xor((int) (unsigned) (tot >> 32), m);
+                tot += ((unsigned long long) hi << 32) | lo;
+            }
+            const unsigned used = uni(hs->used);
+            const int pos = __builtin_ffs((int) (~used & ((1u << RIM_HEY_STASH) - 1u))) - 1;      // hey_post left room
+            wv_sync();
+            if (lane == 0 && pos >= 0) {
+                hs->a[pos] = a; hs->b[pos] = b;
+                hs->v[pos][0] = a1; hs->v[pos][1] = e1; hs->v[pos][2] = s1;
+                hs->v[pos][3] = a2; hs->v[pos][4] = e2; hs->v[pos][5] = s2;
+                hs->status[pos] = st;
+                hs->samples[pos] = tot;
+                hs->used = used | (1u << pos);
+            }
+            wv_sync();
+        }
+        if (nr > 1 && chunk_done && dropped_samples) {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const unsigned lo = (unsigned) wv_shfl_xor((int) (unsigned) unused, m), hi = (unsigned) wv_shfl_xor((int) (unsigned) (unused >> 32), m);
+                unused += ((unsigned long long) hi << 32) | lo;
+            }
+            *dropped_samples += ((unsigned long long) (unsigned) wv_readfirstlane((int) (unsigned) (unused >> 32)) << 32) |
+                                (unsigned) wv_readfirstlane((int) (unsigned) unused);
+        }
     }
     if (!chunk_done) { T.phase = HP_QAG_BISECT; return; }
+    if (hs && uni(hs->used)) {
+        // the quadrature is over: whatever is still on file belongs to it and is dropped -- the samples that went into it
+        // were never part of the coefficient (the launch's sample count is the reference's: dropped_samples come off it)
+        const unsigned used = uni(hs->used);
+        unsigned long long drop = 0;
+        for (int k = 0; k < RIM_HEY_STASH; k++)
+            if ((used >> k) & 1u) drop += hs->samples[k];
+        if (dropped_samples) *dropped_samples += ((unsigned long long) (unsigned) wv_readfirstlane((int) (unsigned) (drop >> 32)) << 32) |
+                                                  (unsigned) wv_readfirstlane((int) (unsigned) drop);
+        wv_sync();
+        if (lane == 0) hs->used = 0;
+        wv_sync();
+    }
 
     // .unwrap_or(NAN) of the outer integral (heyvaerts.rs:204-211, 253-260)
     double contrib = T.oq.result;

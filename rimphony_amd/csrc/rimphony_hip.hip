@@ -133,15 +133,22 @@ struct SymphonyProblem {
     static __device__ __forceinline__ int early_metric(const Task &) { return 0; }
     static __device__ __forceinline__ void uniformize(Task &T) { task_uniformize(T); }
     static __device__ __forceinline__ bool done(const Task &T) { return T.phase == PH_DONE; }
-    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
+    struct Stash { unsigned used; };        // (rounds are the Faraday kernel's: HeyvaertsProblem)
+    enum { TURBO = 0 };
+    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B, Stash *, int)
     { sym_post(c.pt, g, outer, T, B); }
+    static __device__ __forceinline__ int round_n(const Stash &) { return 1; }
+    static __device__ __forceinline__ void round_drop(Stash &) {}
+    static __device__ __forceinline__ double round_request(const Stash &, const GKLane &, int) { return 0.; }
+
     // one or two requests ((x1, tag1) only if have1): two gamma-integrals share their first rule application
     static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, Park *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
     { sym_eval_pair<KIND, PREC>(c.pt, c.d, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
-                                                   const SymBatch &B, double gval, int bst)
+                                                   const SymBatch &B, double gval, int bst, Stash *, unsigned long long *, unsigned long long *,
+                                                   const AssistSlot *, int, int)
     { sym_consume(c.pt, g, outer, T, B, gval, bst); }
     static __device__ __forceinline__ double result(const Ctx &c, const Task &T, int &st) { return sym_result(c.pt, T, st); }
 };
@@ -192,15 +199,28 @@ struct HeyvaertsProblem {
     { return (T.phase == HP_QAG_BISECT || T.phase == HP_QAG_FIRST) ? T.oq.size : 0; }
     static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
-    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B)
-    { hey_post(c.pt, g, outer, T, B); }
+    typedef HeyStash Stash;
+    enum { TURBO = 1 };
+    // rounds (heyvaerts_wave.h): a long outer quadrature's batch carries the children of up to RIM_TURBO_MAX intervals
+    static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B, Stash *hs, int rounds)
+    { hey_post(c.pt, g, outer, T, B, hs, rounds); }
+    static __device__ __forceinline__ int round_n(const Stash &hs) { return uni(hs.round_n); }
+    static __device__ __forceinline__ void round_drop(Stash &hs) { hs.round_n = 1; hs.hit = -1; }
+    static __device__ __forceinline__ double round_request(const Stash &hs, const GKLane &g, int j) { return hey_round_request(&hs, g, j); }
+    // file the sums of the round's further intervals: lane `rank`-th request of interval j sits at 62 j + rank of the slot
     static __device__ __forceinline__ void eval2(const Ctx &c, const GKLane &g, const IStore &inner, Park *qp,
                                                  double x0, int tag0, double x1, int tag1, bool have1,
                                                  double &v0, int &st0, double &v1, int &st1)
     { hey_eval_pair<KIND>(c.pt, c.d, c.hc, g, inner, qp, x0, tag0, x1, tag1, have1, v0, st0, v1, st1); }
     static __device__ __forceinline__ void consume(const Ctx &c, const GKLane &g, const IStore &outer, Task &T,
-                                                   const SymBatch &B, double gval, int bst)
-    { hey_consume(c.pt, g, outer, T, B, gval, bst); }
+                                                   const SymBatch &B, double gval, int bst, Stash *hs, unsigned long long *stash_samples,
+                                                   unsigned long long *dropped_samples, const AssistSlot *slot, int rank, int per)
+    {
+        // (a round's further intervals: their values, status bits and sample counts are read from the owner's board slot)
+        HeyRoundIO io;
+        io.res = slot->res; io.res_status = slot->res_status; io.res_samples = slot->res_samples; io.rank = rank; io.per = per;
+        hey_consume(c.pt, g, outer, T, B, gval, bst, hs, stash_samples, dropped_samples, &io);
+    }
     static __device__ __forceinline__ double result(const Ctx &, const Task &T, int &st) { return hey_result(T, st); }
 };
 
@@ -223,7 +243,10 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
     const IStore outer = istore_carve(s_outer, CAP_OUTER, spill + RIM_ISTORE_DOUBLES(SPILL_INNER), SPILL_OUTER);
     __shared__ typename P::Park s_qpark;
     __shared__ double s_extra[P::EXTRA_LDS_DOUBLES];
-    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; }
+    __shared__ typename P::Stash s_stash;       // rounds of a long outer quadrature (Faraday kernel; heyvaerts_wave.h)
+    if (threadIdx.x == 0) { s_qpark.ctr = WaveCounters{0, 0, 0}; s_qpark.hb = nullptr; s_stash.used = 0; P::round_drop(s_stash); }
+    bool last_shared = false;                   // the previous batch of the own task went over the board: the next may carry a round
+    int round_n = 1;                            // intervals whose children the current batch evaluates
 
     AssistSlot *const my = a.board + blockIdx.x;
     unsigned *const flag_exhausted = a.board_flags + BOARD_FLAG_EXHAUSTED;
@@ -331,9 +354,10 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 }
                 typename P::Task T0;
                 P::begin(cx, T0);
-                if (lane == 0) s_park = T0;
+                if (lane == 0) { s_park = T0; s_stash.used = 0; }
                 __syncthreads();
                 have_task = true;
+                last_shared = false;
 #if defined(RIM_TAIL_DIAG)
                 task_t0 = wall_clock64();
 #endif
@@ -343,9 +367,10 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             {
                 typename P::Task T = s_park;
                 P::uniformize(T);
-                if (!P::done(T)) P::post(cx, g, outer, T, B);
+                if (!P::done(T)) P::post(cx, g, outer, T, B, &s_stash, (P::TURBO && a.turbo && last_shared && !board_dead) ? RIM_TURBO_MAX - 1 : 0);
                 finished = P::done(T);
                 task_batches = P::early_metric(T);
+                round_n = P::TURBO ? P::round_n(s_stash) : 1;
                 if (finished) {
                     int st = 0;
                     const double val = P::result(cx, T, st);
@@ -435,6 +460,16 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             }
             const int cnt = __builtin_popcountll(mask);
             shared = (exhausted ? idle != 0 : champion) && cnt >= 2 && !board_dead;
+            if (P::TURBO) {
+                if (cnt != 0) last_shared = shared;     // (a bisection booked from the stash posts nothing and changes nothing)
+                if (round_n > 1 && !shared) {
+                    // the round was planned for a batch that does not go over the board after all: the picked interval only
+                    __syncthreads();
+                    if (lane == 0) P::round_drop(s_stash);
+                    __syncthreads();
+                    round_n = 1;
+                }
+            }
 #if defined(RIM_TAIL_DIAG)     // (tools/tail_times.py: when the longest outer quadrature passed 64 / 512 / 2048 subintervals, and how
                                // many of its batches were published as the champion's)
             if (P::QUEUE && lane == 0) {
@@ -448,10 +483,16 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 seq += 1;
                 src_seq = seq;
                 COOP_DIAG(n_shared_batches += 1;)
+                if (P::TURBO && round_n > 1) __syncthreads();      // lane 0's copy of the task state (the round's intervals) is visible
                 if (B.req_active) {
                     const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                     bput(&my->req_n[rank], rim_bits(B.req_n));
                     bput(&my->req_lobe[rank], B.req_lobe);
+                    // a round: the children of the further intervals, `cnt` requests each, behind the picked interval's
+                    for (int j = 1; j < round_n; j++) {
+                        bput(&my->req_n[cnt * j + rank], rim_bits(P::round_request(s_stash, g, j)));
+                        bput(&my->req_lobe[cnt * j + rank], B.req_lobe);
+                    }
                 }
                 if (lane == 0) {
                     bput(&my->point, (unsigned long long) own_i);
@@ -461,7 +502,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 drain_vmem();
                 __syncthreads();
                 if (lane == 0)
-                    __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) cnt << 8),
+                    __hip_atomic_store(&my->claim, ((unsigned long long) seq << 32) | ((unsigned long long) (cnt * round_n) << 8),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 drain_vmem();          // the claim word is out before anybody can see the hint
                 __syncthreads();
@@ -576,6 +617,10 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 }
                 n = uni(rim_frombits(bget(&src->req_n[k])));
                 lb = __builtin_amdgcn_readfirstlane(bget(&src->req_lobe[k]));
+            } else if (P::TURBO && shared && k >= __builtin_popcountll(mask)) {
+                // a request of one of the round's further intervals: it only exists on the board
+                n = uni(rim_frombits(bget(&my->req_n[k])));
+                lb = __builtin_amdgcn_readfirstlane(bget(&my->req_lobe[k]));
             } else {
                 const int kl = shared ? kth_set_bit(mask, k) : k;     // lane that posted the request
                 n = readlane_d(B.req_n, kl);
@@ -600,14 +645,14 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             COOP_DIAG(const unsigned long long e0 = wall_clock64();)
             RIM_PROF_T(t_req);
             unsigned long long samples_before = 0;
-            if (a.work && lane == 0) samples_before = s_qpark.ctr.samples;
+            if ((a.work || P::TURBO) && lane == 0) samples_before = s_qpark.ctr.samples;     // (rounds book a request's samples too)
             P::eval2(cx, g, inner, &s_qpark, n, lb, n2, lb2, k2 >= 0, val, st, val2, st2);
             // Work counters count what went INTO the stored value: a request evaluated for the board is booked by
             // the owner when it reads the result, so a batch the owner gives up on and evaluates again is counted once.
             unsigned long long samples_taken = 0;
-            if (a.work && lane == 0) {
+            if ((a.work || P::TURBO) && lane == 0) {
                 samples_taken = s_qpark.ctr.samples - samples_before;
-                if (!shared) atomicAdd(a.work + own_i * 8 + (size_t) own_slot, samples_taken);
+                if (a.work && !shared) atomicAdd(a.work + own_i * 8 + (size_t) own_slot, samples_taken);
             }
             RIM_PROF_ADD(9, t_req);
             COOP_DIAG(eval_ticks += wall_clock64() - e0;)
@@ -615,7 +660,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 if (lane == 0) {
                     bput(&src->res[k], rim_bits(val));
                     bput(&src->res_status[k], st);
-                    if (a.work) bput(&src->res_samples[k], (unsigned) samples_taken);
+                    if (a.work || P::TURBO) bput(&src->res_samples[k], (unsigned) samples_taken);
                     drain_vmem();
                     __hip_atomic_fetch_add(&src->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -629,7 +674,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
 
         // ---------- owner: collect a shared batch ----------
         if (shared) {
-            const unsigned want = (unsigned) __builtin_popcountll(mask);
+            const unsigned want = (unsigned) (__builtin_popcountll(mask) * round_n);
             const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
             bool complete = false;
             const unsigned long long t0 = wall_clock64();
@@ -663,6 +708,12 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
                 // and never publishes again: whatever a late helper still writes to this slot is never read.
                 board_dead = true;
                 shared = false;
+                if (P::TURBO && round_n > 1) {
+                    __syncthreads();
+                    if (lane == 0) P::round_drop(s_stash);
+                    __syncthreads();
+                    round_n = 1;
+                }
                 local_mask = mask;
                 batch_status = 0;
                 gval = 0.;
@@ -688,7 +739,16 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
         {
             typename P::Task T = s_park;
             P::uniformize(T);
-            P::consume(cx, g, outer, T, B, gval, uni(batch_status));
+            unsigned long long stash_samples = 0, dropped_samples = 0;
+            P::consume(cx, g, outer, T, B, gval, uni(batch_status), &s_stash, &stash_samples, &dropped_samples, my,
+                       __builtin_popcountll(mask & ((1ull << lane) - 1ull)), __builtin_popcountll(mask));
+            if (P::TURBO) {
+                // (work counters count what went INTO the stored value: a bisection booked from the stash brings its samples)
+                if (a.work && lane == 0 && stash_samples) atomicAdd(a.work + own_i * 8 + (size_t) own_slot, stash_samples);
+                // the launch's sample count is the reference's: what was evaluated ahead and never asked for comes off it
+                // (counted by whichever wave evaluated it; the counters are summed modulo 2^64 at the end of the launch)
+                if (dropped_samples && lane == 0) s_qpark.ctr.samples -= dropped_samples;
+            }
             __syncthreads();
             if (lane == 0) s_park = T;
             __syncthreads();
@@ -976,6 +1036,7 @@ struct rimphony_ctx {
     int f32_variant;                // RIMPHONY_F32_VARIANT=1: accept RIMPHONY_PRECISION_F32_INTEGRAND (measurement hook)
     int sym_solo;                   // RIMPHONY_SYM_SOLO=1: one wave per (point, coefficient), the round-2 kernel (A/B measurements)
     int faraday_symphony_order;     // RIMPHONY_FARADAY_ORDER=symphony: the Faraday launch visits the points in the Symphony order (A/B measurements)
+    int rounds;                     // RIMPHONY_ROUNDS=0: a long outer quadrature evaluates one interval per batch, as until round 4 (A/B measurements)
     int early_squad;                // RIMPHONY_EARLY_SQUAD: waves of the Faraday grid that serve the longest chain from the start (0: off; -1: the kind's default)
     int early_min;                  // RIMPHONY_EARLY_MIN: batches after which a task competes for that help
     int faraday_group;              // RIMPHONY_FARADAY_GROUP=1: rho_Q and rho_V of a point in lock-step (measured slower: DESIGN.md section 5)
@@ -1088,6 +1149,7 @@ extern "C" int rimphony_ctx_create(int device, rimphony_ctx **out)
     { const char *e = getenv("RIMPHONY_NO_ASSIST"); c->no_assist = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_SYM_SOLO"); c->sym_solo = (e && e[0] == '1'); }
     { const char *e = getenv("RIMPHONY_FARADAY_ORDER"); c->faraday_symphony_order = (e && e[0] == 's'); }
+    { const char *e = getenv("RIMPHONY_ROUNDS"); c->rounds = (e && e[0] == '0') ? 0 : 1; }
     { const char *e = getenv("RIMPHONY_EARLY_SQUAD"); c->early_squad = e ? atoi(e) : -1; if (c->early_squad > 1024) c->early_squad = 1024; }
     { const char *e = getenv("RIMPHONY_EARLY_MIN"); c->early_min = e ? atoi(e) : 16; if (c->early_min < 1) c->early_min = 1; }
     { const char *e = getenv("RIMPHONY_F32_VARIANT"); c->f32_variant = (e && e[0] == '1'); }
@@ -1291,6 +1353,7 @@ static int launch_coop(rimphony_ctx *c, const SymArgs &a, hipStream_t st, hipEve
     b.early_stride = 1;
     b.early_classes = 1;
     b.early_min = c->early_min;
+    b.turbo = c->rounds;
     const unsigned want_squad = c->early_squad >= 0 ? (unsigned) c->early_squad : (unsigned) P::EARLY_SQUAD;
     if (P::EARLY_HELP && b.board && !c->shared_mode && want_squad && ntasks >= 4ull * grid && grid >= 16u * want_squad) {
         b.early_stride = (grid / want_squad) | 1u;
@@ -1532,6 +1595,7 @@ static int batch_compute_locked(rimphony_ctx *c, int kind, size_t n, const doubl
     a.early_stride = 1;
     a.early_classes = 1;
     a.early_min = 0;
+    a.turbo = 0;
     if (d_work) HIP_TRY(hipMemsetAsync(d_work, 0, n * 8 * sizeof(uint64_t), st));
     a.nslots = 0;
     uint32_t computed = 0;

@@ -118,6 +118,9 @@ __device__ __forceinline__ void task_uniformize(TaskState &T)
 // Splitting it this way lets the kernel hand the requests of a batch to OTHER waves once the task
 // queue has run dry (cooperative tail, rimphony_hip.hip) while keeping one copy of the integrand.
 
+// the most intervals whose children one batch of a long outer quadrature evaluates (heyvaerts_wave.h, "rounds")
+#define RIM_TURBO_MAX 4
+
 struct SymBatch {
     double req_n;        // per lane
     int req_lobe;        // per lane

@@ -339,14 +339,17 @@ def test_early_help_and_faraday_order_change_no_bit(gpu_ctx):
     """The Faraday launch's scheduling knobs (round 4): its own visiting order (the window 0.9 <= s sin(theta) <= 3 first,
     then ascending; RIMPHONY_FARADAY_ORDER=symphony restores the shared one) and the squad that serves the longest outer
     quadratures from the start of a launch (coop_common.h; RIMPHONY_EARLY_SQUAD = 0 / 64 / 256: off, one title, four
-    titles).  Who evaluates a request, and when, never changes its value: the same 12288 power-law and pitchy-kappa rows
+    titles), and the ROUNDS of a long outer quadrature (heyvaerts_wave.h: the children of up to four intervals per batch,
+    their rule sums filed ahead of qag.c's picks; RIMPHONY_ROUNDS=0: one interval per batch).  Who evaluates a request, and
+    when, never changes its value: the same 12288 power-law and pitchy-kappa rows
     (enough tasks for the squad to be switched on: four per wave of the grid) give the same table and status words, bit
     for bit, under every setting.  Each leg on a context that owns the device."""
     from rimphony_amd import api
     for cfg in ("cfg2_powerlaw_8", "cfg5_pitchykappa_8"):
         kind, _, s, th, params = workload.make_batch(cfg, 12288, start=1131072 if cfg == "cfg2_powerlaw_8" else 0)
         ref = None
-        for env in ({"RIMPHONY_EARLY_SQUAD": "0", "RIMPHONY_FARADAY_ORDER": "symphony"}, {"RIMPHONY_EARLY_SQUAD": "0"},
+        for env in ({"RIMPHONY_EARLY_SQUAD": "0", "RIMPHONY_FARADAY_ORDER": "symphony", "RIMPHONY_ROUNDS": "0"}, {"RIMPHONY_EARLY_SQUAD": "0"},
+                    {"RIMPHONY_ROUNDS": "0"},
                     {"RIMPHONY_EARLY_SQUAD": "64", "RIMPHONY_EARLY_MIN": "4"}, {"RIMPHONY_EARLY_SQUAD": "256", "RIMPHONY_EARLY_MIN": "4"}, {}):
             with gpu_ctx.released():
                 os.environ.update(env)
