@@ -120,8 +120,8 @@ typedef struct rimphony_ctx rimphony_ctx;
  * 0 for the other two distributions; only on launches with at least four tasks per wave, never in shared mode),
  * RIMPHONY_EARLY_MIN=<n> the size from which an outer quadrature competes for them (16), RIMPHONY_FARADAY_ORDER=symphony
  * makes the Faraday launch visit the points in the Symphony launch's order; RIMPHONY_ROUNDS=0 makes a long outer
- * quadrature of the Faraday kernel evaluate one interval per batch (default: the children of up to four, their rule sums
- * filed ahead of qag.c's picks).  Scheduling only: the tables do not change.
+ * quadrature of the pitchy-kappa Faraday kernel evaluate one interval per batch (default: the children of up to four, their
+ * rule sums filed ahead of qag.c's picks; the other distributions' kernels are built without rounds).  Scheduling only: the tables do not change.
  * RIMPHONY_OWNER_WAIT_US=<n> (test hook) shortens the 120 s an owner wave waits for its helpers before it recomputes
  * a published batch itself; results do not depend on it. */
 int rimphony_ctx_create(int device, rimphony_ctx **out);

@@ -200,8 +200,12 @@ struct HeyvaertsProblem {
     static __device__ __forceinline__ void uniformize(Task &T) { hey_uniformize(T); }
     static __device__ __forceinline__ bool done(const Task &T) { return T.stage == HS_DONE; }
     typedef HeyStash Stash;
-    enum { TURBO = 1 };
-    // rounds (heyvaerts_wave.h): a long outer quadrature's batch carries the children of up to RIM_TURBO_MAX intervals
+    // rounds (heyvaerts_wave.h): a long outer quadrature's batch carries the children of up to RIM_TURBO_MAX intervals.
+    // Compiled in for the pitchy-kappa distribution only: that is where they pay (four quadratures of 2844 .. 4132 batches
+    // and a dozen of 300 .. 760 in 65536 rows: -20 .. -26 % on its Faraday launches); the power-law table's long
+    // quadratures are hidden by the squad already, the other two tables have none -- and the code costs a kernel that
+    // never sees a round about 1 % (profiles/r4_ab_rounds.txt).
+    enum { TURBO = KIND == DIST_PITCHY_KAPPA ? 1 : 0 };
     static __device__ __forceinline__ void post(const Ctx &c, const GKLane &g, const IStore &outer, Task &T, SymBatch &B, Stash *hs, int rounds)
     { hey_post(c.pt, g, outer, T, B, hs, rounds); }
     static __device__ __forceinline__ int round_n(const Stash &hs) { return uni(hs.round_n); }
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             {
                 typename P::Task T = s_park;
                 P::uniformize(T);
-                if (!P::done(T)) P::post(cx, g, outer, T, B, &s_stash, (P::TURBO && a.turbo && last_shared && !board_dead) ? RIM_TURBO_MAX - 1 : 0);
+                if (!P::done(T)) P::post(cx, g, outer, T, B, P::TURBO ? &s_stash : nullptr, (P::TURBO && a.turbo && last_shared && !board_dead) ? RIM_TURBO_MAX - 1 : 0);
                 finished = P::done(T);
                 task_batches = P::early_metric(T);
                 round_n = P::TURBO ? P::round_n(s_stash) : 1;
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(64, P::WAVES) void coop_kernel(SymArgs a)
             typename P::Task T = s_park;
             P::uniformize(T);
             unsigned long long stash_samples = 0, dropped_samples = 0;
-            P::consume(cx, g, outer, T, B, gval, uni(batch_status), &s_stash, &stash_samples, &dropped_samples, my,
+            P::consume(cx, g, outer, T, B, gval, uni(batch_status), P::TURBO ? &s_stash : nullptr, &stash_samples, &dropped_samples, my,
                        __builtin_popcountll(mask & ((1ull << lane) - 1ull)), __builtin_popcountll(mask));
             if (P::TURBO) {
                 // (work counters count what went INTO the stored value: a bisection booked from the stash brings its samples)
