@@ -141,7 +141,9 @@ def main(argv=None):
     ap.add_argument("outfile")
     ap.add_argument("ranges", nargs="+", type=float, help="MIN MAX pairs in the order of the reference driver")
     ap.add_argument("--count", type=int, default=0, help="rows to write (0 = run forever, like the reference)")
-    ap.add_argument("--block", type=int, default=16384)
+    # the end of a launch (its longest chains of batches) takes about as long whatever the block's size: large blocks amortise
+    # it -- pitchy kappa: 6.8 k rows/s in 16384-row blocks, 11.8 k rows/s in 625000-row ones (profiles/r4_full_size_*.txt)
+    ap.add_argument("--block", type=int, default=262144, help="rows per launch (per GPU with --gpus)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to shard each block over")
     args = ap.parse_args(argv)

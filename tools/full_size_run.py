@@ -16,6 +16,8 @@ from rimphony_amd import api, workload
 
 args = sys.argv[1:]
 cfg, rows = args[0], int(float(args[1]))
+# (--tile: the end of a launch costs about the same whatever the tile's size, so large tiles amortise it: 1e7 thermal rows
+# 299 s in 131072-row tiles, 288 s in 1048576-row ones; the committed profiles name the tile they were run with)
 opt = {"--tile": 131072, "--world": 1, "--rank": 0, "--start": 0}
 for k in list(opt):
     if k in args:
