@@ -348,6 +348,7 @@ def test_early_help_and_faraday_order_change_no_bit(gpu_ctx):
     for cfg in ("cfg2_powerlaw_8", "cfg5_pitchykappa_8"):
         kind, _, s, th, params = workload.make_batch(cfg, 12288, start=1131072 if cfg == "cfg2_powerlaw_8" else 0)
         ref = None
+        works = []
         for env in ({"RIMPHONY_EARLY_SQUAD": "0", "RIMPHONY_FARADAY_ORDER": "symphony", "RIMPHONY_ROUNDS": "0"}, {"RIMPHONY_EARLY_SQUAD": "0"},
                     {"RIMPHONY_ROUNDS": "0"},
                     {"RIMPHONY_EARLY_SQUAD": "64", "RIMPHONY_EARLY_MIN": "4"}, {"RIMPHONY_EARLY_SQUAD": "256", "RIMPHONY_EARLY_MIN": "4"}, {}):
@@ -361,6 +362,7 @@ def test_early_help_and_faraday_order_change_no_bit(gpu_ctx):
                 try:
                     assert not ctx.shared_mode()
                     out, st = ctx.compute_batch(kind, s, th, params, 0xC0, want_status=True)
+                    works.append(ctx.last_work())
                 finally:
                     ctx.close()
             if ref is None:
@@ -368,6 +370,16 @@ def test_early_help_and_faraday_order_change_no_bit(gpu_ctx):
             else:
                 assert same_bits(out[:, 6:], ref[0][:, 6:]).all(), (cfg, env)
                 assert (st[:, 6:] == ref[1][:, 6:]).all(), (cfg, env)
+        # the launch's sample count is the reference's under every setting (what a round evaluates ahead and nobody asks for
+        # comes off it) -- and the rounds did run where they are compiled in: the pitchy-kappa launches evaluated inner
+        # integrals that the plain ones (settings 0 and 2: RIMPHONY_ROUNDS=0) did not (the children of intervals that
+        # were filed and never picked); the power-law kernel is built without rounds
+        assert len({w["faraday_samples"] for w in works}) == 1, (cfg, [w["faraday_samples"] for w in works])
+        q = [w["faraday_inner_qags"] for w in works]
+        if cfg == "cfg5_pitchykappa_8":
+            assert q[0] == q[2] and min(q[1], q[3], q[4]) > q[0], q
+        else:
+            assert len(set(q)) == 1, q
 
 
 def test_kernel_variants_change_no_bit(gpu_ctx):
